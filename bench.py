@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — particle-steps/s of the PBF-SPH hot path on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--particles P] [--fp64] [--fast-math]
+
+A "step" is one advance() (predict+key, counting sort + cell table, diffuse, K_s = 4 x (lambda,
+delta-p), finalise) over the device-resident particle state of the dam-break scene
+(N = 1: 1 M nominal = 1 024 000 particles, BASELINE.json configs[2]).  Inputs are
+resident in HBM when the timed region starts; the PCIe-inclusive advance() rate is reported
+separately by the C++ benchmark CLI and in DESIGN.md, never as `value`.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     — the dominant kernel's algorithmic bytes / its mean HIP-event duration
+  cpu_baseline — the CPU oracle (kind "port", OpenMP) timed on a bounded sample of the same workload.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+# algorithmic bytes per particle for one launch of each stage (fp32; fp64 doubles
+# the float fields, 4-byte keys/indices stay).
+STAGE_BYTES_F32 = {"advect+zindex": 52, "sortz+gridtable": 132, "sph-diffuse": 32, "sph-lambda": 16, "sph-delta": 28,
+                   "sph-finalise": 60}
+STAGE_BYTES_F64 = {"advect+zindex": 100, "sortz+gridtable": 256, "sph-diffuse": 64, "sph-lambda": 32,
+                   "sph-delta": 56, "sph-finalise": 120}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def load_package():
+    pkg_dir = os.path.join(ROOT, "pbf-sph_amd")
+    spec = importlib.util.spec_from_file_location("pbf_sph_amd", os.path.join(pkg_dir, "__init__.py"),
+                                                  submodule_search_locations=[pkg_dir])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["pbf_sph_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_baseline(state, side, fp64, iteration, budget_s=20.0, max_steps=8):
+    """Time the oracle (the checker, kind 'port') on the host cores: a bounded sample of the SAME
+    workload, started from the GPU's post-warm-up state.  Reported, never optimised against."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    threads = len(os.sched_getaffinity(0))
+    o = O.Oracle(fp64)
+    o.set_particles(**state)
+    q = O.make_params(iteration=iteration, max_bound=(side,) * 3, mode=O.JACOBI, sort=O.SORT_STABLE, threads=threads)
+    n = len(state["id"])
+    t0 = time.perf_counter()
+    o.step(q)  # untimed: first touch / OpenMP pool start
+    first = time.perf_counter() - t0
+    steps, t = 0, 0.0
+    while steps < max_steps and (steps == 0 or t + t / steps < budget_s - first):
+        a = time.perf_counter()
+        o.step(q)
+        t += time.perf_counter() - a
+        steps += 1
+    return {"value": n * steps / t, "unit": "particle-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} steps of the same {n}-particle dam-break state after warm-up "
+                      f"(oracle Jacobi mode, OpenMP, -O2 no fast-math), {t:.1f} s",
+            "ms_per_step": 1e3 * t / steps}, o
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--particles", type=int, default=1 << 20, help="nominal particle count per GPU (dam-break)")
+    ap.add_argument("--solver-iter", type=int, default=4)
+    ap.add_argument("--fp64", action="store_true")
+    ap.add_argument("--fast-math", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = load_package()
+    flags = pkg.FLAG_STAGE_TIMING | (pkg.FLAG_FAST_MATH if args.fast_math else 0)
+    scene, side = pkg.scene_dambreak(args.particles, args.fp64)
+    n = len(scene["id"])
+    solver = pkg.Solver(h=0.1, fp64=args.fp64, device=local_rank, flags=flags)
+    solver.upload(**scene)
+    p = pkg.default_params(args.solver_iter, side)
+
+    def barrier():
+        solver.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    solver.steps(p, args.warmup)
+    barrier()
+    solver.reset_stage_times()
+    t0 = time.perf_counter()
+    solver.steps(p, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stage = solver.stage_times()
+
+    if rank == 0:
+        total_particles = n * world
+        value = total_particles * args.steps / elapsed
+        sb = STAGE_BYTES_F64 if args.fp64 else STAGE_BYTES_F32
+        # dominant kernel = the stage with the largest total time per step
+        per_step = {k: ms * calls / args.steps for k, (ms, calls) in stage.items()}
+        dom = max(per_step, key=per_step.get)
+        dom_ms, dom_calls = stage[dom]
+        achieved = sb[dom] * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        bytes_step = (276 + 44 * args.solver_iter) if not args.fp64 else (528 + 88 * args.solver_iter)
+        out = {
+            "metric": "particle-steps/sec (1 M particles, 4 iters) + achieved HBM GB/s, 1/2/4/8 MI355X",
+            "value": value,
+            "unit": "particle-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if args.fp64 else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"dam-break, {n} particles/GPU (nominal {args.particles}), box {side:.0f}^3, "
+                                   f"h=0.1, K={args.solver_iter}, dt=0.01245, scale=500",
+                       "particles": total_particles, "solver_iter": args.solver_iter,
+                       "math": "fast (v_rsq, fma)" if args.fast_math else "precise (IEEE div/sqrt, no contraction)",
+                       "parallelism": "1 GPU, device-resident" if world == 1 else
+                                      f"{world} independent replicas (slab decomposition + RCCL halo: pending)"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_particle": sb[dom], "mean_launch_ms": dom_ms,
+                         "launches_timed": dom_calls,
+                         "whole_step_GBs": value * bytes_step / 1e9 / world,
+                         "note": "neighbour kernels are LDS/VALU/latency-bound, not HBM-bound (SURVEY.md §8d)"},
+            "stage_ms_per_step": per_step,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            state = solver.download()
+            cb, o = cpu_baseline(state, side, args.fp64, args.solver_iter)
+            # the oracle is also the checker: one more GPU step from the same state must agree
+            solver.step(p)
+            g = solver.download()
+            o2_state = None
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib as O
+                oo = O.Oracle(args.fp64)
+                oo.set_particles(**state)
+                oo.step(O.make_params(iteration=args.solver_iter, max_bound=(side,) * 3, mode=O.JACOBI,
+                                      sort=O.SORT_STABLE, threads=cb["cores"]))
+                o2_state = oo.get_particles()
+            except Exception as e:  # the check is informative here; tests/ are the gate
+                out["parity_check_error"] = str(e)
+            if o2_state is not None:
+                gi, wi = np.argsort(g["id"]), np.argsort(o2_state["id"])
+                d = np.linalg.norm(g["pos"][gi].astype(np.float64) - o2_state["pos"][wi], axis=1)
+                out["parity_check_max_dx_world_units"] = float(d.max())
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = value / cb["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,146 @@
+/*
+ * pbf_hip.h — C ABI of libpbf_hip.so: the MI355X (gfx950) implementation of the PBF-SPH
+ * per-step hot path behind the reference's Solver::advance() surface.
+ *
+ * The reference has no FFI: its backends are C++ classes chosen by a switch
+ * (src/benchmark.cpp:105-172) behind
+ *     sph::Solver<T,N,V>::advance(const SphParams&, const Scene&, std::vector<Particle>&)
+ * (src/sph.hpp:119-125).  This header is the boundary a maintainer binds a new backend to;
+ * pbf-sph_amd/host/hipsph.hpp is that binding (sph::hip_impl::Solver<T,N>, a thin shim), and
+ * INTEGRATION.md shows the lines to add to the reference's benchmark.cpp / args.hpp.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  Every function returns 0 on
+ * success or a negative pbf_status; pbf_last_error() gives the text.  Nothing throws across
+ * the ABI (reference: exceptions, src/benchmark.cpp:32-37).  One ctx = one caller thread at a
+ * time (the reference's advance() has no thread-safety contract either, src/visualise.cpp:85-109).
+ * Arrays are caller-owned SoA: pos/vel 3 per particle, colour 4 per particle, element type
+ * float (fp64 = 0) or double (fp64 = 1) as chosen in pbf_desc (reference: template parameter N,
+ * src/specialisation.cpp:13-14).  ids are uint64 (reference T = size_t).
+ */
+#ifndef PBF_HIP_H
+#define PBF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBF_ABI_VERSION 1
+
+typedef struct pbf_ctx pbf_ctx;
+
+typedef enum pbf_status {
+  PBF_OK = 0,
+  PBF_ERR_INVALID = -1,   /* bad argument */
+  PBF_ERR_HIP = -2,       /* a HIP runtime call failed (text in pbf_last_error) */
+  PBF_ERR_NO_DEVICE = -3, /* no gfx950 device / HIP runtime unusable: the product path never falls back to CPU */
+  PBF_ERR_STATE = -4,     /* call order violated (e.g. stage before upload) */
+  PBF_ERR_COMM = -5,      /* RCCL failure */
+} pbf_status;
+
+/* sph::Type (src/sph.hpp:15) */
+enum { PBF_TYPE_FLUID = 0, PBF_TYPE_OBSTACLE = 1 };
+
+enum {
+  PBF_FLAG_STAGE_TIMING = 1u << 0, /* record hipEvents around every stage (Stopwatch analogue, src/utils.hpp:15-57) */
+  PBF_FLAG_FAST_MATH = 1u << 1,    /* v_rsq/v_rcp in the pair kernels (the reference itself ships -Ofast,
+                                      CMakeLists.txt:136, and native_divide/fast_distance in OpenCL) */
+  PBF_FLAG_NO_LDS = 1u << 2,       /* force the per-particle global-memory gather kernels (debug / A-B) */
+};
+
+/* Replaces the ctor  omp_impl::Solver<T,N>(N h)  (src/omp/ompsph.hpp:83). */
+typedef struct pbf_desc {
+  uint32_t abi_version; /* PBF_ABI_VERSION */
+  int32_t fp64;         /* 0: N = float, 1: N = double (benchmark --fp64, src/args.cpp:34-37) */
+  int32_t device;       /* HIP device ordinal (benchmark -d, src/args.cpp:20-24) */
+  uint32_t flags;       /* PBF_FLAG_* */
+  double h;             /* smoothing length; benchmark.cpp:160-163 passes 0.1 */
+  void *stream;         /* hipStream_t to launch on; NULL = a stream owned by the ctx */
+} pbf_desc;
+
+/* Replaces sph::SphParams (src/sph.hpp:97-103) + sph::Scene::wells (src/sph.hpp:56-60,76).
+ * SphParams::h is dead in the reference (src/sph.hpp:98, never read) and therefore absent. */
+typedef struct pbf_params {
+  double dt, scale;
+  uint64_t iteration;       /* solver iterations K */
+  double constant_force[3];
+  double min_bound[3], max_bound[3];
+  int32_t n_wells;
+  const double *wells;      /* n_wells x {cx, cy, cz, force}, host */
+  int32_t xsph, vorticity;  /* opt-in, NOT in the reference (only constants survive, src/sph_constants.h:13-14) */
+} pbf_params;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+int pbf_create(const pbf_desc *desc, pbf_ctx **out);
+void pbf_destroy(pbf_ctx *ctx);
+/* ctx may be NULL: last error of a failed pbf_create on this thread */
+const char *pbf_last_error(const pbf_ctx *ctx);
+int pbf_abi_version(void);
+
+/* ---- particle state (replaces the std::vector<Particle>& in/out argument, src/sph.hpp:124) */
+int pbf_upload(pbf_ctx *ctx, size_t n, const uint64_t *id, const uint8_t *type, const void *mass, const void *pos,
+               const void *vel, const void *colour);
+/* Device order = Z-sorted after a step, exactly like the reference's write-back
+ * (src/omp/ompsph.hpp:479-481).  Any pointer may be NULL. */
+int pbf_download(pbf_ctx *ctx, uint64_t *id, uint8_t *type, void *mass, void *pos, void *vel, void *colour);
+size_t pbf_count(const pbf_ctx *ctx);
+
+/* AoS path for the C++ shim: `particles` is the caller's std::vector<Particle>::data()
+ * (src/sph.hpp:36-54).  Unpacked / repacked on the device; offsets in bytes. */
+typedef struct pbf_aos_layout {
+  uint32_t stride, off_id, off_type, off_mass, off_pos, off_vel, off_colour;
+} pbf_aos_layout;
+int pbf_upload_aos(pbf_ctx *ctx, size_t n, const void *particles, const pbf_aos_layout *layout);
+int pbf_download_aos(pbf_ctx *ctx, void *particles, const pbf_aos_layout *layout);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+/* One advance() on device-resident state (src/omp/ompsph.hpp:128-271 + 479-481), asynchronous
+ * on the ctx stream: predict+key -> counting sort + cell table -> diffuse -> K x (lambda, delta)
+ * -> finalise.  The two loops the reference updates in place (racy with >1 thread,
+ * src/omp/ompsph.hpp:188-207,235-248) are double-buffered (Jacobi) here. */
+int pbf_step(pbf_ctx *ctx, const pbf_params *params);
+int pbf_steps(pbf_ctx *ctx, const pbf_params *params, uint32_t count); /* count x pbf_step, no host sync */
+int pbf_sync(pbf_ctx *ctx);
+
+/* Stage-level entry points: exactly the launches pbf_step makes, exposed so that each kernel
+ * can be checked against the oracle stage by stage.  Order as in pbf_step. */
+int pbf_stage_predict(pbf_ctx *ctx, const pbf_params *params);  /* ompsph.hpp:132-154 */
+int pbf_stage_sort(pbf_ctx *ctx, const pbf_params *params);     /* ompsph.hpp:157-165, sph.hpp:238-250 */
+int pbf_stage_diffuse(pbf_ctx *ctx, const pbf_params *params);  /* ompsph.hpp:188-207 */
+int pbf_stage_lambda(pbf_ctx *ctx, const pbf_params *params);   /* ompsph.hpp:217-232 */
+int pbf_stage_delta(pbf_ctx *ctx, const pbf_params *params);    /* ompsph.hpp:235-248 */
+int pbf_stage_finalise(pbf_ctx *ctx, const pbf_params *params); /* ompsph.hpp:256-264 */
+
+/* ---- introspection (parity tests, Stopwatch analogue) ------------------------------------ */
+enum pbf_buffer {
+  PBF_BUF_KEYS = 0,   /* uint32[n]  Morton cell key per particle, current device order */
+  PBF_BUF_TABLE = 1,  /* uint32[table_size] = the reference's gridTable (sph.hpp:238-250) */
+  PBF_BUF_PSTAR = 2,  /* N[4n]: pStar.xyz, lambda */
+  PBF_BUF_COUNT_ = 3,
+};
+int pbf_read_buffer(pbf_ctx *ctx, int which, void *host, size_t bytes);
+size_t pbf_table_size(const pbf_ctx *ctx);                /* Morton(extent), sph.hpp:240 */
+int pbf_grid_extent(const pbf_ctx *ctx, uint64_t extent[3], double min_extent[3]); /* ompsph.hpp:132-135 */
+
+/* Mean milliseconds per call of each stage since the last pbf_reset_stage_times (needs
+ * PBF_FLAG_STAGE_TIMING).  names[i] points at static strings that follow the reference's Stopwatch
+ * entries (ompsph.hpp:130,157,161,188,209,252).  Returns the number of stages (<= cap). */
+int pbf_stage_times(pbf_ctx *ctx, const char **names, double *mean_ms, uint64_t *calls, int cap);
+int pbf_reset_stage_times(pbf_ctx *ctx);
+
+/* ---- scene factory (sph.hpp:127-186; dam-break: SURVEY.md §8d) — host only, no GPU needed -- */
+size_t pbf_scene_cubes(int fp64, size_t count, uint64_t *id, uint8_t *type, void *mass, void *pos, void *vel,
+                       void *colour);
+size_t pbf_scene_dambreak(int fp64, size_t nominal, uint64_t *id, uint8_t *type, void *mass, void *pos, void *vel,
+                          void *colour, double *box_side);
+/* applyMotionSinXCosZ (sph.hpp:147-158): writes min/max bound of `base` shifted for `frame` into `out` */
+void pbf_apply_motion(int fp64, const pbf_params *base, uint64_t frame, pbf_params *out);
+/* simpleConfigWith2Cubes' SphParams (sph.hpp:168-175) with K = iteration */
+void pbf_default_params(uint64_t iteration, double box_side, pbf_params *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,725 @@
+// pbf_hip.hip — context, launch sequence and C ABI (include/pbf_hip.h) of the gfx950 PBF-SPH step.
+//
+// The product path: there is NO CPU fallback anywhere in this file.  If no HIP device is usable
+// pbf_create fails with PBF_ERR_NO_DEVICE and every other entry point needs a ctx.
+#include "pbf_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pbf_kernels.hpp"
+
+using namespace pbf;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+enum Stage { ST_PREDICT = 0, ST_SORT, ST_DIFFUSE, ST_LAMBDA, ST_DELTA, ST_FINALISE, ST_COUNT };
+// names follow the reference's Stopwatch entries (ompsph.hpp:130,157,161,188,209,252)
+const char *kStageNames[ST_COUNT] = {"advect+zindex",      "sortz+gridtable", "sph-diffuse",
+                                     "sph-lambda",         "sph-delta",       "sph-finalise"};
+
+struct EventPair {
+  hipEvent_t a, b;
+  int stage;
+};
+
+}  // namespace
+
+struct pbf_ctx {
+  pbf_desc desc{};
+  int device = 0;
+  bool fp64 = false;
+  bool fast = false;
+  hipStream_t stream = nullptr;
+  bool ownStream = false;
+  std::string err;
+
+  size_t n = 0;
+  size_t cap = 0;        // particle capacity of the SoA buffers
+  bool hasObstacles = false;
+  bool sorted = false;   // keys/table valid for the current arrays
+  bool counted = false;  // cell histogram of the current keys is in `count` (set by predict, consumed by sort)
+  int cur = 0;           // which of the two particle-array sets is live
+  int pcur = 0;          // which pstar buffer is live
+  // two sets (sort scatters from one into the other)
+  DevBuf pos4[2], vel4[2], col4[2], id[2], type[2], key[2];
+  DevBuf pstar[3];       // [0],[1]: sort ping-pong partner of set 0/1 ; [2]: Jacobi partner
+  DevBuf count, table, blockSums, permTmp, wells, staging;
+  size_t tableCap = 0;   // entries allocated in count/table
+  uint32_t tableN = 0;
+  uint32_t countedTableN = 0;
+  uint64_t extent[3] = {0, 0, 0};
+  double minExtent[3] = {0, 0, 0};
+
+  // stage timing
+  std::vector<EventPair> pending;
+  std::vector<hipEvent_t> freeEvents;
+  double stageMs[ST_COUNT] = {0};
+  uint64_t stageCalls[ST_COUNT] = {0};
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                          \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                              \
+      return PBF_ERR_HIP;                                                                          \
+    }                                                                                              \
+  } while (0)
+
+int fail(pbf_ctx *ctx, int code, const std::string &msg) {
+  ctx->err = msg;
+  return code;
+}
+
+int ensure(pbf_ctx *ctx, DevBuf &b, size_t bytes, bool zero = false) {
+  if (b.cap >= bytes) return PBF_OK;
+  void *np = nullptr;
+  const size_t want = bytes + bytes / 4 + 256;
+  HIPCHK(ctx, hipMalloc(&np, want));
+  if (zero) HIPCHK(ctx, hipMemsetAsync(np, 0, want, ctx->stream));
+  if (b.p) {
+    // contents are never carried across a grow: callers refill
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(b.p));
+  }
+  b.p = np;
+  b.cap = want;
+  return PBF_OK;
+}
+
+template <typename N> size_t vsz() { return sizeof(vec4<N>); }
+
+int ensure_particles(pbf_ctx *ctx, size_t n) {
+  if (ctx->cap >= n) return PBF_OK;
+  const size_t v = ctx->fp64 ? sizeof(double4) : sizeof(float4);
+  for (int s = 0; s < 2; ++s) {
+    if (int rc = ensure(ctx, ctx->pos4[s], n * v)) return rc;
+    if (int rc = ensure(ctx, ctx->vel4[s], n * v)) return rc;
+    if (int rc = ensure(ctx, ctx->col4[s], n * v)) return rc;
+    if (int rc = ensure(ctx, ctx->id[s], n * 8)) return rc;
+    if (int rc = ensure(ctx, ctx->type[s], n)) return rc;
+    if (int rc = ensure(ctx, ctx->key[s], n * 4)) return rc;
+  }
+  for (int s = 0; s < 3; ++s)
+    if (int rc = ensure(ctx, ctx->pstar[s], n * v)) return rc;
+  if (int rc = ensure(ctx, ctx->permTmp, n * 4)) return rc;
+  ctx->cap = n;
+  return PBF_OK;
+}
+
+template <typename N> ParticleArrays<N> arrays(pbf_ctx *ctx, int set, int pstarIdx) {
+  ParticleArrays<N> a;
+  a.pos4 = ctx->pos4[set].as<vec4<N>>();
+  a.vel4 = ctx->vel4[set].as<vec4<N>>();
+  a.col4 = ctx->col4[set].as<vec4<N>>();
+  a.pstar = ctx->pstar[pstarIdx].as<vec4<N>>();
+  a.id = ctx->id[set].as<uint64_t>();
+  a.type = ctx->type[set].as<uint8_t>();
+  a.key = ctx->key[set].as<uint32_t>();
+  return a;
+}
+
+// ---- per-step constants, in N, as the reference computes them ---------------------------------
+template <typename N> N piN() { return std::acos(-N(1)); }
+// sph.hpp:251-253 — std::pow(N, int) promotes to double for N = float; the result is rounded to N
+template <typename N> N poly6_factor(N h) { return N(N(315.0) / (N(64.0) * piN<N>() * std::pow(h, 9))); }
+template <typename N> N spiky_factor(N h) { return N(-(N(45.0) / (piN<N>() * std::pow(h, 6)))); }
+
+template <typename N> int make_consts(pbf_ctx *ctx, const pbf_params *p, StepConsts<N> &c) {
+  const N h = N(ctx->desc.h), scale = N(p->scale);
+  c.h = h, c.dt = N(p->dt), c.scale = scale;
+  // ompsph.hpp:132-135
+  const N padding = h * 2;
+  uint64_t ext[3];
+  for (int i = 0; i < 3; ++i) {
+    c.force[i] = N(p->constant_force[i]);
+    c.minB[i] = N(p->min_bound[i]);
+    c.maxB[i] = N(p->max_bound[i]);
+    const N lo = c.minB[i] / scale - padding;
+    const N hi = c.maxB[i] / scale + padding;
+    c.minExtent[i] = lo;
+    ext[i] = static_cast<uint64_t>((hi - lo) / h);
+    ctx->minExtent[i] = double(lo);
+  }
+  for (int i = 0; i < 3; ++i) {
+    if (ext[i] > 1023)
+      return fail(ctx, PBF_ERR_INVALID, "grid extent exceeds the 10-bit-per-axis Morton range (curves.h:72-88)");
+    ctx->extent[i] = ext[i];
+  }
+  c.tableN = morton_encode(uint32_t(ext[0]), uint32_t(ext[1]), uint32_t(ext[2]));  // sph.hpp:240
+  if (c.tableN == 0) return fail(ctx, PBF_ERR_INVALID, "empty grid (max_bound <= min_bound?)");
+  c.poly6Factor = poly6_factor<N>(h);
+  c.spikyFactor = spiky_factor<N>(h);
+  {  // ompsph.hpp:213 with poly6Kernel of ompsph.hpp:67-69
+    const N r = N(CorrDeltaQ * h);
+    const N d = (h * h) - r * r;
+    c.p6DeltaQ = r <= h ? c.poly6Factor * (d * d * d) : N(0);
+  }
+  c.diffuseT = c.dt / N(750.0);
+  c.n = uint32_t(ctx->n);
+  c.nWells = uint32_t(p->n_wells > 0 ? p->n_wells : 0);
+  c.hasObstacles = ctx->hasObstacles ? 1u : 0u;
+  ctx->tableN = c.tableN;
+  return PBF_OK;
+}
+
+// A histogram that was built but never consumed (predict without sort) must not leak into the next one.
+int drop_histogram(pbf_ctx *ctx) {
+  if (ctx->counted && ctx->count.p) HIPCHK(ctx, hipMemsetAsync(ctx->count.p, 0, ctx->count.cap, ctx->stream));
+  ctx->counted = false;
+  return PBF_OK;
+}
+
+int ensure_table(pbf_ctx *ctx, uint32_t tableN) {
+  const size_t entries = size_t(tableN) + 2;  // buckets 0..tableN (+1 overflow) and the closing total
+  if (ctx->tableCap >= entries) return PBF_OK;
+  // count must start (and, by the atomicSub in k_scatter_slots, always returns to) all-zero
+  ctx->count.cap = 0;
+  if (ctx->count.p) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(ctx->count.p));
+    ctx->count.p = nullptr;
+  }
+  if (int rc = ensure(ctx, ctx->count, (entries + SCAN_TILE) * 4, true)) return rc;
+  if (int rc = ensure(ctx, ctx->table, (entries + SCAN_TILE) * 4)) return rc;
+  const size_t nb = (entries + SCAN_TILE - 1) / SCAN_TILE + 1;
+  if (int rc = ensure(ctx, ctx->blockSums, nb * 4)) return rc;
+  ctx->tableCap = ctx->count.cap / 4 - SCAN_TILE;
+  return PBF_OK;
+}
+
+// ---- stage timing (Stopwatch analogue, utils.hpp:15-57) ----------------------------------------
+hipEvent_t get_event(pbf_ctx *ctx) {
+  if (!ctx->freeEvents.empty()) {
+    hipEvent_t e = ctx->freeEvents.back();
+    ctx->freeEvents.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+int resolve_events(pbf_ctx *ctx) {
+  if (ctx->pending.empty()) return PBF_OK;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto &ep : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+      ctx->stageMs[ep.stage] += ms;
+      ctx->stageCalls[ep.stage] += 1;
+    }
+    ctx->freeEvents.push_back(ep.a);
+    ctx->freeEvents.push_back(ep.b);
+  }
+  ctx->pending.clear();
+  return PBF_OK;
+}
+struct StageTimer {
+  pbf_ctx *ctx;
+  EventPair ep{};
+  bool on;
+  StageTimer(pbf_ctx *c, int stage) : ctx(c), on((c->desc.flags & PBF_FLAG_STAGE_TIMING) != 0) {
+    if (!on) return;
+    ep.a = get_event(ctx), ep.b = get_event(ctx), ep.stage = stage;
+    (void)hipEventRecord(ep.a, ctx->stream);
+  }
+  ~StageTimer() {
+    if (!on) return;
+    (void)hipEventRecord(ep.b, ctx->stream);
+    ctx->pending.push_back(ep);
+    if (ctx->pending.size() > 8192) (void)resolve_events(ctx);
+  }
+};
+
+inline dim3 grid_for(size_t n) { return dim3(unsigned((n + BLOCK - 1) / BLOCK)); }
+
+#define LAUNCH_CHECK(ctx)                                                  \
+  do {                                                                     \
+    hipError_t e_ = hipGetLastError();                                     \
+    if (e_ != hipSuccess) {                                                \
+      (ctx)->err = std::string("kernel launch: ") + hipGetErrorString(e_); \
+      return PBF_ERR_HIP;                                                  \
+    }                                                                      \
+  } while (0)
+
+int upload_wells(pbf_ctx *ctx, const pbf_params *p) {
+  if (p->n_wells <= 0) return PBF_OK;
+  if (!p->wells) return fail(ctx, PBF_ERR_INVALID, "n_wells > 0 but wells == NULL");
+  const size_t cnt = size_t(p->n_wells) * 4;
+  const size_t esz = ctx->fp64 ? 8 : 4;
+  if (int rc = ensure(ctx, ctx->wells, cnt * esz)) return rc;
+  if (ctx->fp64) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->wells.p, p->wells, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    std::vector<float> w(cnt);
+    for (size_t i = 0; i < cnt; ++i) w[i] = float(p->wells[i]);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->wells.p, w.data(), cnt * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // w is a temporary
+  }
+  return PBF_OK;
+}
+
+// ---- stages ------------------------------------------------------------------------------------
+template <typename N> int stage_predict(pbf_ctx *ctx, const pbf_params *p) {
+  StepConsts<N> c;
+  if (int rc = make_consts<N>(ctx, p, c)) return rc;
+  if (int rc = ensure_table(ctx, c.tableN)) return rc;
+  if (int rc = drop_histogram(ctx)) return rc;
+  if (int rc = upload_wells(ctx, p)) return rc;
+  StageTimer t(ctx, ST_PREDICT);
+  const int s = ctx->cur;
+  hipLaunchKernelGGL((k_predict<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c,
+                     ctx->pos4[s].as<const vec4<N>>(), ctx->vel4[s].as<vec4<N>>(), ctx->type[s].as<const uint8_t>(),
+                     ctx->wells.as<const N>(), ctx->pstar[s].as<vec4<N>>(), ctx->key[s].as<uint32_t>(),
+                     ctx->count.as<uint32_t>());
+  LAUNCH_CHECK(ctx);
+  ctx->pcur = s;
+  ctx->sorted = false;
+  ctx->counted = true;
+  ctx->countedTableN = c.tableN;
+  return PBF_OK;
+}
+
+template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
+  // the scatter consumes the histogram k_predict built (atomicSub back to zero): never run it twice
+  if (!ctx->counted) return fail(ctx, PBF_ERR_STATE, "pbf_stage_sort needs pbf_stage_predict first");
+  StepConsts<N> c;
+  if (int rc = make_consts<N>(ctx, p, c)) return rc;
+  if (c.tableN != ctx->countedTableN) return fail(ctx, PBF_ERR_STATE, "bounds changed between predict and sort");
+  StageTimer t(ctx, ST_SORT);
+  const uint32_t len = c.tableN + 2;
+  const uint32_t nb = (len + SCAN_TILE - 1) / SCAN_TILE;
+  uint32_t *count = ctx->count.as<uint32_t>(), *table = ctx->table.as<uint32_t>(),
+           *sums = ctx->blockSums.as<uint32_t>();
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(BLOCK), 0, ctx->stream, count, len, sums);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLOCK), 0, ctx->stream, sums, nb);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(BLOCK), 0, ctx->stream, count, len, sums, table);
+  const int s = ctx->cur, d = 1 - s;
+  hipLaunchKernelGGL(k_scatter_slots, grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c.n, c.tableN,
+                     ctx->key[s].as<const uint32_t>(), table, count, ctx->permTmp.as<uint32_t>());
+  hipLaunchKernelGGL((k_rank_move<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c.n, c.tableN,
+                     ctx->permTmp.as<const uint32_t>(), table, arrays<N>(ctx, s, s), arrays<N>(ctx, d, d));
+  LAUNCH_CHECK(ctx);
+  ctx->cur = d;
+  ctx->pcur = d;
+  ctx->sorted = true;
+  ctx->counted = false;
+  return PBF_OK;
+}
+
+// the Jacobi partner of pstar[pcur]: any of the three buffers that is neither live nor needed
+inline int other_pstar(const pbf_ctx *ctx) { return ctx->pcur == 2 ? ctx->cur : 2; }
+
+template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p) {
+  StepConsts<N> c;
+  if (int rc = make_consts<N>(ctx, p, c)) return rc;
+  StageTimer t(ctx, ST_DIFFUSE);
+  const int s = ctx->cur, d = 1 - s;  // col4[d] is free after the sort
+  hipLaunchKernelGGL((k_diffuse<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c,
+                     ctx->key[s].as<const uint32_t>(), ctx->table.as<const uint32_t>(),
+                     ctx->type[s].as<const uint8_t>(), ctx->col4[s].as<const vec4<N>>(), ctx->col4[d].as<vec4<N>>());
+  LAUNCH_CHECK(ctx);
+  std::swap(ctx->col4[s], ctx->col4[d]);
+  return PBF_OK;
+}
+
+template <typename N> int stage_lambda(pbf_ctx *ctx, const pbf_params *p) {
+  StepConsts<N> c;
+  if (int rc = make_consts<N>(ctx, p, c)) return rc;
+  StageTimer t(ctx, ST_LAMBDA);
+  const int s = ctx->cur;
+  auto launch = [&](auto fastTag) {
+    constexpr bool FAST = decltype(fastTag)::value;
+    hipLaunchKernelGGL((k_lambda<N, FAST>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c,
+                       ctx->key[s].as<const uint32_t>(), ctx->table.as<const uint32_t>(),
+                       ctx->type[s].as<const uint8_t>(), ctx->pos4[s].as<const vec4<N>>(),
+                       ctx->pstar[ctx->pcur].as<vec4<N>>());
+  };
+  if (ctx->fast) launch(std::true_type{}); else launch(std::false_type{});
+  LAUNCH_CHECK(ctx);
+  return PBF_OK;
+}
+
+template <typename N> int stage_delta(pbf_ctx *ctx, const pbf_params *p) {
+  StepConsts<N> c;
+  if (int rc = make_consts<N>(ctx, p, c)) return rc;
+  StageTimer t(ctx, ST_DELTA);
+  const int s = ctx->cur, in = ctx->pcur, out = other_pstar(ctx);
+  auto launch = [&](auto fastTag) {
+    constexpr bool FAST = decltype(fastTag)::value;
+    hipLaunchKernelGGL((k_delta<N, FAST>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c,
+                       ctx->key[s].as<const uint32_t>(), ctx->table.as<const uint32_t>(),
+                       ctx->type[s].as<const uint8_t>(), ctx->pstar[in].as<const vec4<N>>(),
+                       ctx->pstar[out].as<vec4<N>>());
+  };
+  if (ctx->fast) launch(std::true_type{}); else launch(std::false_type{});
+  LAUNCH_CHECK(ctx);
+  ctx->pcur = out;
+  return PBF_OK;
+}
+
+template <typename N> int stage_finalise(pbf_ctx *ctx, const pbf_params *p) {
+  StepConsts<N> c;
+  if (int rc = make_consts<N>(ctx, p, c)) return rc;
+  StageTimer t(ctx, ST_FINALISE);
+  const int s = ctx->cur;
+  hipLaunchKernelGGL((k_finalise<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c,
+                     ctx->type[s].as<const uint8_t>(), ctx->pstar[ctx->pcur].as<const vec4<N>>(),
+                     ctx->pos4[s].as<vec4<N>>(), ctx->vel4[s].as<vec4<N>>());
+  LAUNCH_CHECK(ctx);
+  // keep pstar[cur] as the live buffer so that a later sort scatters pstar[cur] -> pstar[1-cur]
+  if (ctx->pcur != s) {
+    std::swap(ctx->pstar[ctx->pcur], ctx->pstar[s]);
+    ctx->pcur = s;
+  }
+  return PBF_OK;
+}
+
+template <typename N> int step_impl(pbf_ctx *ctx, const pbf_params *p) {
+  if (ctx->n == 0) return PBF_OK;  // "Particles depleted" (ompsph.hpp:122-126)
+  if (int rc = stage_predict<N>(ctx, p)) return rc;
+  if (int rc = stage_sort<N>(ctx, p)) return rc;
+  if (int rc = stage_diffuse<N>(ctx, p)) return rc;
+  for (uint64_t it = 0; it < p->iteration; ++it) {
+    if (int rc = stage_lambda<N>(ctx, p)) return rc;
+    if (int rc = stage_delta<N>(ctx, p)) return rc;
+  }
+  return stage_finalise<N>(ctx, p);
+}
+
+int check(pbf_ctx *ctx, const pbf_params *p, bool needSorted) {
+  if (!ctx) return PBF_ERR_INVALID;
+  if (!p) return fail(ctx, PBF_ERR_INVALID, "params == NULL");
+  if (!(p->scale > 0) || !(p->dt > 0)) return fail(ctx, PBF_ERR_INVALID, "dt and scale must be > 0");
+  if (needSorted && !ctx->sorted) return fail(ctx, PBF_ERR_STATE, "stage needs pbf_stage_sort first");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return PBF_OK;
+}
+
+template <typename N>
+int upload_impl(pbf_ctx *ctx, size_t n, const uint64_t *id, const uint8_t *type, const N *mass, const N *pos,
+                const N *vel, const N *colour) {
+  if (int rc = ensure_particles(ctx, n)) return rc;
+  if (int rc = drop_histogram(ctx)) return rc;
+  ctx->cur = 0, ctx->pcur = 0, ctx->sorted = false;
+  ctx->n = n;
+  ctx->hasObstacles = false;
+  if (n == 0) return PBF_OK;
+  std::vector<vec4<N>> P(n), V(n), C(n);
+  for (size_t i = 0; i < n; ++i) {
+    P[i] = make_vec4<N>(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], mass[i]);
+    V[i] = make_vec4<N>(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2], N(0));
+    C[i] = make_vec4<N>(colour[4 * i], colour[4 * i + 1], colour[4 * i + 2], colour[4 * i + 3]);
+    if (type[i] == PBF_TYPE_OBSTACLE) ctx->hasObstacles = true;
+  }
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pos4[0].p, P.data(), n * sizeof(vec4<N>), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->vel4[0].p, V.data(), n * sizeof(vec4<N>), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->col4[0].p, C.data(), n * sizeof(vec4<N>), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->id[0].p, id, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->type[0].p, type, n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // P, V, C are temporaries
+  return PBF_OK;
+}
+
+template <typename N>
+int download_impl(pbf_ctx *ctx, uint64_t *id, uint8_t *type, N *mass, N *pos, N *vel, N *colour) {
+  const size_t n = ctx->n;
+  if (n == 0) return PBF_OK;
+  const int s = ctx->cur;
+  std::vector<vec4<N>> tmp(n);
+  if (mass || pos) {
+    HIPCHK(ctx, hipMemcpyAsync(tmp.data(), ctx->pos4[s].p, n * sizeof(vec4<N>), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < n; ++i) {
+      if (pos) pos[3 * i] = tmp[i].x, pos[3 * i + 1] = tmp[i].y, pos[3 * i + 2] = tmp[i].z;
+      if (mass) mass[i] = tmp[i].w;
+    }
+  }
+  if (vel) {
+    HIPCHK(ctx, hipMemcpyAsync(tmp.data(), ctx->vel4[s].p, n * sizeof(vec4<N>), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < n; ++i) vel[3 * i] = tmp[i].x, vel[3 * i + 1] = tmp[i].y, vel[3 * i + 2] = tmp[i].z;
+  }
+  if (colour) {
+    HIPCHK(ctx, hipMemcpyAsync(colour, ctx->col4[s].p, n * sizeof(vec4<N>), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (id) HIPCHK(ctx, hipMemcpyAsync(id, ctx->id[s].p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (type) HIPCHK(ctx, hipMemcpyAsync(type, ctx->type[s].p, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PBF_OK;
+}
+
+}  // namespace
+
+#define DISPATCH(ctx, fn, ...) ((ctx)->fp64 ? fn<double>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
+
+extern "C" {
+
+int pbf_abi_version(void) { return PBF_ABI_VERSION; }
+
+int pbf_create(const pbf_desc *desc, pbf_ctx **out) {
+  if (!desc || !out) {
+    g_create_error = "pbf_create: NULL argument";
+    return PBF_ERR_INVALID;
+  }
+  *out = nullptr;
+  if (desc->abi_version != PBF_ABI_VERSION) {
+    g_create_error = "pbf_create: abi_version mismatch";
+    return PBF_ERR_INVALID;
+  }
+  if (!(desc->h > 0)) {
+    g_create_error = "pbf_create: h must be > 0";
+    return PBF_ERR_INVALID;
+  }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_create_error = std::string("pbf_create: no usable HIP device (") + hipGetErrorString(e) +
+                     "); this library has no CPU fallback";
+    return PBF_ERR_NO_DEVICE;
+  }
+  if (desc->device < 0 || desc->device >= count) {
+    g_create_error = "pbf_create: device ordinal out of range";
+    return PBF_ERR_INVALID;
+  }
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, desc->device)) != hipSuccess) {
+    g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+    return PBF_ERR_HIP;
+  }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("pbf_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+    return PBF_ERR_NO_DEVICE;
+  }
+  auto *ctx = new pbf_ctx();
+  ctx->desc = *desc;
+  ctx->device = desc->device;
+  ctx->fp64 = desc->fp64 != 0;
+  ctx->fast = (desc->flags & PBF_FLAG_FAST_MATH) != 0;
+  if ((e = hipSetDevice(ctx->device)) != hipSuccess) {
+    g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    delete ctx;
+    return PBF_ERR_HIP;
+  }
+  if (desc->stream) {
+    ctx->stream = static_cast<hipStream_t>(desc->stream);
+  } else {
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+      g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+      delete ctx;
+      return PBF_ERR_HIP;
+    }
+    ctx->ownStream = true;
+  }
+  *out = ctx;
+  return PBF_OK;
+}
+
+void pbf_destroy(pbf_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &ep : ctx->pending) {
+    (void)hipEventDestroy(ep.a);
+    (void)hipEventDestroy(ep.b);
+  }
+  for (auto ev : ctx->freeEvents) (void)hipEventDestroy(ev);
+  DevBuf *all[] = {&ctx->pos4[0], &ctx->pos4[1], &ctx->vel4[0], &ctx->vel4[1], &ctx->col4[0],  &ctx->col4[1],
+                   &ctx->id[0],   &ctx->id[1],   &ctx->type[0], &ctx->type[1], &ctx->key[0],   &ctx->key[1],
+                   &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2], &ctx->count, &ctx->table,   &ctx->blockSums,
+                   &ctx->permTmp, &ctx->wells,   &ctx->staging};
+  for (DevBuf *b : all)
+    if (b->p) (void)hipFree(b->p);
+  if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *pbf_last_error(const pbf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int pbf_upload(pbf_ctx *ctx, size_t n, const uint64_t *id, const uint8_t *type, const void *mass, const void *pos,
+               const void *vel, const void *colour) {
+  if (!ctx) return PBF_ERR_INVALID;
+  if (n && (!id || !type || !mass || !pos || !vel || !colour)) return fail(ctx, PBF_ERR_INVALID, "NULL array");
+  if (n >= (size_t(1) << 31)) return fail(ctx, PBF_ERR_INVALID, "n must be < 2^31 (ompsph.hpp:41 iterates with int)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->fp64)
+    return upload_impl<double>(ctx, n, id, type, (const double *)mass, (const double *)pos, (const double *)vel,
+                               (const double *)colour);
+  return upload_impl<float>(ctx, n, id, type, (const float *)mass, (const float *)pos, (const float *)vel,
+                            (const float *)colour);
+}
+
+int pbf_download(pbf_ctx *ctx, uint64_t *id, uint8_t *type, void *mass, void *pos, void *vel, void *colour) {
+  if (!ctx) return PBF_ERR_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->fp64)
+    return download_impl<double>(ctx, id, type, (double *)mass, (double *)pos, (double *)vel, (double *)colour);
+  return download_impl<float>(ctx, id, type, (float *)mass, (float *)pos, (float *)vel, (float *)colour);
+}
+
+size_t pbf_count(const pbf_ctx *ctx) { return ctx ? ctx->n : 0; }
+
+int pbf_upload_aos(pbf_ctx *ctx, size_t n, const void *particles, const pbf_aos_layout *l) {
+  if (!ctx) return PBF_ERR_INVALID;
+  if (!l || (n && !particles)) return fail(ctx, PBF_ERR_INVALID, "NULL argument");
+  if (n >= (size_t(1) << 31)) return fail(ctx, PBF_ERR_INVALID, "n must be < 2^31");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (int rc = ensure_particles(ctx, n)) return rc;
+  if (int rc = drop_histogram(ctx)) return rc;
+  ctx->cur = 0, ctx->pcur = 0, ctx->sorted = false, ctx->n = n;
+  ctx->hasObstacles = false;
+  if (n == 0) return PBF_OK;
+  const uint8_t *src = static_cast<const uint8_t *>(particles);
+  for (size_t i = 0; i < n; ++i)
+    if (src[i * l->stride + l->off_type] == PBF_TYPE_OBSTACLE) {
+      ctx->hasObstacles = true;
+      break;
+    }
+  if (int rc = ensure(ctx, ctx->staging, n * l->stride)) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->staging.p, particles, n * l->stride, hipMemcpyHostToDevice, ctx->stream));
+  AosLayout L{l->stride, l->off_id, l->off_type, l->off_mass, l->off_pos, l->off_vel, l->off_colour};
+  if (ctx->fp64)
+    hipLaunchKernelGGL((k_unpack_aos<double>), grid_for(n), dim3(BLOCK), 0, ctx->stream, uint32_t(n),
+                       ctx->staging.as<const uint8_t>(), L, arrays<double>(ctx, 0, 0));
+  else
+    hipLaunchKernelGGL((k_unpack_aos<float>), grid_for(n), dim3(BLOCK), 0, ctx->stream, uint32_t(n),
+                       ctx->staging.as<const uint8_t>(), L, arrays<float>(ctx, 0, 0));
+  LAUNCH_CHECK(ctx);
+  return PBF_OK;
+}
+
+int pbf_download_aos(pbf_ctx *ctx, void *particles, const pbf_aos_layout *l) {
+  if (!ctx) return PBF_ERR_INVALID;
+  if (!l || (ctx->n && !particles)) return fail(ctx, PBF_ERR_INVALID, "NULL argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = ctx->n;
+  if (n == 0) return PBF_OK;
+  if (int rc = ensure(ctx, ctx->staging, n * l->stride)) return rc;
+  // padding bytes of the caller's structs are preserved: start from the host image
+  HIPCHK(ctx, hipMemcpyAsync(ctx->staging.p, particles, n * l->stride, hipMemcpyHostToDevice, ctx->stream));
+  AosLayout L{l->stride, l->off_id, l->off_type, l->off_mass, l->off_pos, l->off_vel, l->off_colour};
+  if (ctx->fp64)
+    hipLaunchKernelGGL((k_pack_aos<double>), grid_for(n), dim3(BLOCK), 0, ctx->stream, uint32_t(n),
+                       ctx->staging.as<uint8_t>(), L, arrays<double>(ctx, ctx->cur, ctx->pcur));
+  else
+    hipLaunchKernelGGL((k_pack_aos<float>), grid_for(n), dim3(BLOCK), 0, ctx->stream, uint32_t(n),
+                       ctx->staging.as<uint8_t>(), L, arrays<float>(ctx, ctx->cur, ctx->pcur));
+  LAUNCH_CHECK(ctx);
+  HIPCHK(ctx, hipMemcpyAsync(particles, ctx->staging.p, n * l->stride, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PBF_OK;
+}
+
+int pbf_step(pbf_ctx *ctx, const pbf_params *p) {
+  if (int rc = check(ctx, p, false)) return rc;
+  return DISPATCH(ctx, step_impl, ctx, p);
+}
+int pbf_steps(pbf_ctx *ctx, const pbf_params *p, uint32_t count) {
+  if (int rc = check(ctx, p, false)) return rc;
+  for (uint32_t i = 0; i < count; ++i)
+    if (int rc = DISPATCH(ctx, step_impl, ctx, p)) return rc;
+  return PBF_OK;
+}
+int pbf_sync(pbf_ctx *ctx) {
+  if (!ctx) return PBF_ERR_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PBF_OK;
+}
+
+int pbf_stage_predict(pbf_ctx *ctx, const pbf_params *p) {
+  if (int rc = check(ctx, p, false)) return rc;
+  if (ctx->n == 0) return PBF_OK;
+  return DISPATCH(ctx, stage_predict, ctx, p);
+}
+int pbf_stage_sort(pbf_ctx *ctx, const pbf_params *p) {
+  if (int rc = check(ctx, p, false)) return rc;
+  if (ctx->n == 0) return PBF_OK;
+  return DISPATCH(ctx, stage_sort, ctx, p);
+}
+int pbf_stage_diffuse(pbf_ctx *ctx, const pbf_params *p) {
+  if (int rc = check(ctx, p, true)) return rc;
+  return DISPATCH(ctx, stage_diffuse, ctx, p);
+}
+int pbf_stage_lambda(pbf_ctx *ctx, const pbf_params *p) {
+  if (int rc = check(ctx, p, true)) return rc;
+  return DISPATCH(ctx, stage_lambda, ctx, p);
+}
+int pbf_stage_delta(pbf_ctx *ctx, const pbf_params *p) {
+  if (int rc = check(ctx, p, true)) return rc;
+  return DISPATCH(ctx, stage_delta, ctx, p);
+}
+int pbf_stage_finalise(pbf_ctx *ctx, const pbf_params *p) {
+  if (int rc = check(ctx, p, true)) return rc;
+  return DISPATCH(ctx, stage_finalise, ctx, p);
+}
+
+int pbf_read_buffer(pbf_ctx *ctx, int which, void *host, size_t bytes) {
+  if (!ctx || !host) return PBF_ERR_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const void *src = nullptr;
+  size_t avail = 0;
+  const size_t v = ctx->fp64 ? sizeof(double4) : sizeof(float4);
+  switch (which) {
+    case PBF_BUF_KEYS: src = ctx->key[ctx->cur].p, avail = ctx->n * 4; break;
+    case PBF_BUF_TABLE:
+      if (!ctx->sorted) return fail(ctx, PBF_ERR_STATE, "table not built yet");
+      src = ctx->table.p, avail = size_t(ctx->tableN) * 4;
+      break;
+    case PBF_BUF_PSTAR: src = ctx->pstar[ctx->pcur].p, avail = ctx->n * v; break;
+    default: return fail(ctx, PBF_ERR_INVALID, "unknown buffer");
+  }
+  if (bytes > avail) return fail(ctx, PBF_ERR_INVALID, "read beyond buffer");
+  if (!src) return fail(ctx, PBF_ERR_STATE, "buffer not allocated yet");
+  HIPCHK(ctx, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PBF_OK;
+}
+
+size_t pbf_table_size(const pbf_ctx *ctx) { return ctx ? ctx->tableN : 0; }
+int pbf_grid_extent(const pbf_ctx *ctx, uint64_t extent[3], double min_extent[3]) {
+  if (!ctx) return PBF_ERR_INVALID;
+  for (int i = 0; i < 3; ++i) {
+    if (extent) extent[i] = ctx->extent[i];
+    if (min_extent) min_extent[i] = ctx->minExtent[i];
+  }
+  return PBF_OK;
+}
+
+int pbf_stage_times(pbf_ctx *ctx, const char **names, double *mean_ms, uint64_t *calls, int cap) {
+  if (!ctx) return PBF_ERR_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (int rc = resolve_events(ctx)) return rc;
+  int k = 0;
+  for (; k < ST_COUNT && k < cap; ++k) {
+    if (names) names[k] = kStageNames[k];
+    if (mean_ms) mean_ms[k] = ctx->stageCalls[k] ? ctx->stageMs[k] / double(ctx->stageCalls[k]) : 0.0;
+    if (calls) calls[k] = ctx->stageCalls[k];
+  }
+  return k;
+}
+int pbf_reset_stage_times(pbf_ctx *ctx) {
+  if (!ctx) return PBF_ERR_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (int rc = resolve_events(ctx)) return rc;
+  for (int k = 0; k < ST_COUNT; ++k) ctx->stageMs[k] = 0, ctx->stageCalls[k] = 0;
+  return PBF_OK;
+}
+
+}  // extern "C"

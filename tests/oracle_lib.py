@@ -1,0 +1,278 @@
+"""ctypes binding of oracle/libpbf_oracle.so and oracle/_ref/libref_grid.so.
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product path (pbf-sph_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libpbf_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_grid.so")
+
+GS, JACOBI = 0, 1
+SORT_STD, SORT_STABLE = 0, 1
+
+
+class OracleParams(C.Structure):
+    _fields_ = [
+        ("h", C.c_double),
+        ("dt", C.c_double),
+        ("scale", C.c_double),
+        ("iteration", C.c_uint64),
+        ("constant_force", C.c_double * 3),
+        ("min_bound", C.c_double * 3),
+        ("max_bound", C.c_double * 3),
+        ("mode", C.c_int32),
+        ("sort", C.c_int32),
+        ("threads", C.c_int32),
+        ("xsph", C.c_int32),
+        ("vorticity", C.c_int32),
+        ("n_wells", C.c_int32),
+        ("wells", C.POINTER(C.c_double)),
+    ]
+
+
+def build(force=False):
+    """Compile the checker (make -C oracle). Building the checker is not using it."""
+    if force or not os.path.exists(ORACLE_SO) or (
+        os.path.exists("/root/reference/src/sph.hpp") and not os.path.exists(REF_SO)
+    ):
+        subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+
+
+_lib = None
+_ref = None
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(ORACLE_SO)
+        L.pbf_oracle_create.restype = C.c_void_p
+        L.pbf_oracle_create.argtypes = [C.c_int]
+        L.pbf_oracle_destroy.argtypes = [C.c_void_p]
+        L.pbf_oracle_set_particles.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
+        L.pbf_oracle_count.restype = C.c_size_t
+        L.pbf_oracle_count.argtypes = [C.c_void_p]
+        L.pbf_oracle_get_particles.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        for name in ("step", "predict", "sort", "grid_table", "diffuse", "lambda", "delta", "finalise"):
+            f = getattr(L, "pbf_oracle_" + name)
+            f.argtypes = [C.c_void_p, C.POINTER(OracleParams)]
+            f.restype = C.c_int
+        for name in ("get_keys", "get_pstar", "get_lambda", "get_table"):
+            getattr(L, "pbf_oracle_" + name).argtypes = [C.c_void_p, C.c_void_p]
+        L.pbf_oracle_table_size.restype = C.c_size_t
+        L.pbf_oracle_table_size.argtypes = [C.c_void_p]
+        L.pbf_oracle_get_extent.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pbf_oracle_candidate_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                                 C.POINTER(C.c_double)]
+        L.pbf_oracle_morton_encode.restype = C.c_uint64
+        L.pbf_oracle_morton_encode.argtypes = [C.c_uint64] * 3
+        L.pbf_oracle_morton_decode.restype = C.c_uint64
+        L.pbf_oracle_morton_decode.argtypes = [C.c_uint64, C.c_int]
+        L.pbf_oracle_neighbour_codes.argtypes = [C.c_uint64, C.c_void_p]
+        L.pbf_oracle_poly6_factor.restype = C.c_double
+        L.pbf_oracle_poly6_factor.argtypes = [C.c_int, C.c_double]
+        L.pbf_oracle_spiky_factor.restype = C.c_double
+        L.pbf_oracle_spiky_factor.argtypes = [C.c_int, C.c_double]
+        L.pbf_oracle_scene_cubes.restype = C.c_size_t
+        L.pbf_oracle_scene_cubes.argtypes = [C.c_int, C.c_size_t] + [C.c_void_p] * 5
+        L.pbf_oracle_scene_dambreak.restype = C.c_size_t
+        L.pbf_oracle_scene_dambreak.argtypes = [C.c_int, C.c_size_t] + [C.c_void_p] * 5 + [C.POINTER(C.c_double)]
+        L.pbf_oracle_motion_offset.argtypes = [C.c_int, C.c_uint64, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def ref():
+    """The reference's own glm-free headers, compiled (oracle/_ref). None if unavailable."""
+    global _ref
+    if _ref is None:
+        build()
+        if not os.path.exists(REF_SO):
+            return None
+        R = C.CDLL(REF_SO)
+        R.ref_morton_encode.restype = C.c_uint64
+        R.ref_morton_encode.argtypes = [C.c_uint64] * 3
+        R.ref_morton_decode.restype = C.c_uint64
+        R.ref_morton_decode.argtypes = [C.c_uint64, C.c_int]
+        R.ref_grid_index_at_f32.restype = C.c_uint64
+        R.ref_grid_index_at_f32.argtypes = [C.c_float] * 4
+        R.ref_grid_index_at_f64.restype = C.c_uint64
+        R.ref_grid_index_at_f64.argtypes = [C.c_double] * 4
+        R.ref_make_grid_table.restype = C.c_uint64
+        R.ref_make_grid_table.argtypes = [C.c_uint64] * 4 + [C.c_void_p, C.c_void_p]
+        R.ref_foreach_grid.restype = C.c_uint64
+        R.ref_foreach_grid.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        for nm in ("ref_poly6_factor_f32", "ref_spiky_factor_f32"):
+            getattr(R, nm).restype = C.c_double
+            getattr(R, nm).argtypes = [C.c_float]
+        for nm in ("ref_poly6_factor_f64", "ref_spiky_factor_f64"):
+            getattr(R, nm).restype = C.c_double
+            getattr(R, nm).argtypes = [C.c_double]
+        for nm in ("ref_scene_cubes_f32", "ref_scene_cubes_f64"):
+            getattr(R, nm).restype = C.c_uint64
+            getattr(R, nm).argtypes = [C.c_uint64, C.c_uint64, C.c_double] + [C.c_void_p] * 7
+        R.ref_motion_f32.argtypes = [C.c_uint64, C.c_void_p]
+        R.ref_motion_f64.argtypes = [C.c_uint64, C.c_void_p]
+        R.ref_sizeof_partially_advected_f32.restype = C.c_uint64
+        _ref = R
+    return _ref
+
+
+def make_params(h=0.1, dt=0.0083 * 1.5, scale=500.0, iteration=4, force=(0.0, 9.8, 0.0), min_bound=(0, 0, 0),
+                max_bound=(1000, 1000, 1000), mode=JACOBI, sort=SORT_STABLE, threads=0, xsph=0, vorticity=0,
+                wells=None):
+    """Defaults restate simpleConfigWith2Cubes (sph.hpp:168-175) with K=4 and h=0.1 (benchmark.cpp:160)."""
+    p = OracleParams()
+    p.h, p.dt, p.scale, p.iteration = h, dt, scale, iteration
+    p.constant_force[:] = force
+    p.min_bound[:] = [float(v) for v in min_bound]
+    p.max_bound[:] = [float(v) for v in max_bound]
+    p.mode, p.sort, p.threads, p.xsph, p.vorticity = mode, sort, threads, xsph, vorticity
+    if wells is not None and len(wells):
+        w = np.ascontiguousarray(wells, dtype=np.float64).reshape(-1, 4)
+        p._wells_keepalive = w
+        p.n_wells = w.shape[0]
+        p.wells = w.ctypes.data_as(C.POINTER(C.c_double))
+    else:
+        p.n_wells = 0
+        p.wells = None
+    return p
+
+
+class Oracle:
+    """Stateful CPU oracle (one per precision)."""
+
+    def __init__(self, fp64=False):
+        self.fp64 = bool(fp64)
+        self.dtype = np.float64 if fp64 else np.float32
+        self.L = lib()
+        self.h = C.c_void_p(self.L.pbf_oracle_create(int(self.fp64)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.pbf_oracle_destroy(self.h)
+            self.h = None
+
+    def set_particles(self, id, type, mass, pos, vel, colour):
+        n = len(id)
+        id = np.ascontiguousarray(id, np.uint64)
+        type = np.ascontiguousarray(type, np.uint8)
+        mass = np.ascontiguousarray(mass, self.dtype)
+        pos = np.ascontiguousarray(pos, self.dtype).reshape(n, 3)
+        vel = np.ascontiguousarray(vel, self.dtype).reshape(n, 3)
+        colour = np.ascontiguousarray(colour, self.dtype).reshape(n, 4)
+        self.L.pbf_oracle_set_particles(self.h, n, _vp(id), _vp(type), _vp(mass), _vp(pos), _vp(vel), _vp(colour))
+
+    @property
+    def n(self):
+        return self.L.pbf_oracle_count(self.h)
+
+    def get_particles(self):
+        n = self.n
+        out = dict(id=np.empty(n, np.uint64), type=np.empty(n, np.uint8), mass=np.empty(n, self.dtype),
+                   pos=np.empty((n, 3), self.dtype), vel=np.empty((n, 3), self.dtype),
+                   colour=np.empty((n, 4), self.dtype))
+        self.L.pbf_oracle_get_particles(self.h, _vp(out["id"]), _vp(out["type"]), _vp(out["mass"]), _vp(out["pos"]),
+                                        _vp(out["vel"]), _vp(out["colour"]))
+        return out
+
+    def _stage(self, name, p):
+        rc = getattr(self.L, "pbf_oracle_" + name)(self.h, C.byref(p))
+        assert rc == 0, name
+        return self
+
+    def step(self, p):
+        return self._stage("step", p)
+
+    def predict(self, p):
+        return self._stage("predict", p)
+
+    def sort(self, p):
+        return self._stage("sort", p)
+
+    def grid_table(self, p):
+        return self._stage("grid_table", p)
+
+    def diffuse(self, p):
+        return self._stage("diffuse", p)
+
+    def lambda_(self, p):
+        return self._stage("lambda", p)
+
+    def delta(self, p):
+        return self._stage("delta", p)
+
+    def finalise(self, p):
+        return self._stage("finalise", p)
+
+    def keys(self):
+        k = np.empty(self.n, np.uint64)
+        self.L.pbf_oracle_get_keys(self.h, _vp(k))
+        return k
+
+    def pstar(self):
+        a = np.empty((self.n, 3), self.dtype)
+        self.L.pbf_oracle_get_pstar(self.h, _vp(a))
+        return a
+
+    def lambdas(self):
+        a = np.empty(self.n, self.dtype)
+        self.L.pbf_oracle_get_lambda(self.h, _vp(a))
+        return a
+
+    def table(self):
+        t = np.empty(self.L.pbf_oracle_table_size(self.h), np.uint64)
+        self.L.pbf_oracle_get_table(self.h, _vp(t))
+        return t
+
+    def extent(self):
+        e = np.zeros(3, np.uint64)
+        m = np.zeros(3, self.dtype)
+        self.L.pbf_oracle_get_extent(self.h, _vp(e), _vp(m))
+        return e, m
+
+    def candidate_stats(self):
+        mean, mx, within = C.c_double(), C.c_uint64(), C.c_double()
+        self.L.pbf_oracle_candidate_stats(self.h, C.byref(mean), C.byref(mx), C.byref(within))
+        return mean.value, mx.value, within.value
+
+
+def scene_cubes(count, fp64=False):
+    L = lib()
+    dt = np.float64 if fp64 else np.float32
+    n = L.pbf_oracle_scene_cubes(int(fp64), count, None, None, None, None, None)
+    out = dict(id=np.empty(n, np.uint64), type=np.zeros(n, np.uint8), mass=np.empty(n, dt), pos=np.empty((n, 3), dt),
+               vel=np.empty((n, 3), dt), colour=np.empty((n, 4), dt))
+    L.pbf_oracle_scene_cubes(int(fp64), count, _vp(out["id"]), _vp(out["mass"]), _vp(out["pos"]), _vp(out["vel"]),
+                             _vp(out["colour"]))
+    return out
+
+
+def scene_dambreak(nominal, fp64=False):
+    L = lib()
+    dt = np.float64 if fp64 else np.float32
+    side = C.c_double()
+    n = L.pbf_oracle_scene_dambreak(int(fp64), nominal, None, None, None, None, None, C.byref(side))
+    out = dict(id=np.empty(n, np.uint64), type=np.zeros(n, np.uint8), mass=np.empty(n, dt), pos=np.empty((n, 3), dt),
+               vel=np.empty((n, 3), dt), colour=np.empty((n, 4), dt))
+    L.pbf_oracle_scene_dambreak(int(fp64), nominal, _vp(out["id"]), _vp(out["mass"]), _vp(out["pos"]),
+                                _vp(out["vel"]), _vp(out["colour"]), C.byref(side))
+    return out, side.value
+
+
+def motion_offset(frame, fp64=False):
+    o = np.zeros(3)
+    lib().pbf_oracle_motion_offset(int(fp64), frame, _vp(o))
+    return o

@@ -1,0 +1,110 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/pbf_hip.h
+declares, its host-only helpers (scene factory, box motion, default params) agree with the
+oracle / the reference-generated goldens, and it FAILS LOUDLY without a GPU (no CPU fallback).
+No compute entry point is called here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported(pkg):
+    hdr = open(os.path.join(ROOT, "include", "pbf_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pbf_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"pbf_status"}
+    assert len(declared) >= 25
+    L = C.CDLL(pkg.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    # the Python binding covers the same set
+    from pbf_sph_amd import capi
+    assert set(capi.exported_symbols()) == declared
+
+
+def test_abi_version(pkg):
+    assert pkg.lib().pbf_abi_version() == 1
+
+
+def test_no_oracle_in_product():
+    """The product path must not reference the oracle (test infrastructure)."""
+    for base, _, files in os.walk(os.path.join(ROOT, "pbf-sph_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                assert "pbf_oracle" not in txt and "oracle_lib" not in txt, os.path.join(base, f)
+
+
+@pytest.mark.parametrize("fp64", [False, True])
+def test_scene_cubes_matches_oracle_and_golden(pkg, oracle, golden_dir, fp64):
+    G = np.load(os.path.join(golden_dir, "ref_grid.npz"))
+    nm = "f64" if fp64 else "f32"
+    s = pkg.scene_cubes(2048, fp64)
+    for k in ("id", "mass", "pos", "vel", "colour"):
+        assert np.array_equal(s[k], G[f"scene_2048_{nm}_{k}"]), k
+    assert np.all(s["type"] == 0)
+    for count in (1024, 8192, 20000):
+        a, b = pkg.scene_cubes(count, fp64), oracle.scene_cubes(count, fp64)
+        for k in ("id", "mass", "pos", "vel", "colour"):
+            assert np.array_equal(a[k], b[k])
+
+
+@pytest.mark.parametrize("fp64", [False, True])
+def test_scene_dambreak(pkg, oracle, fp64):
+    # SURVEY §8d sizes: nominal -> (n, L)
+    want = {8192: (8192, 1100.0), 262144: (250000, 2950.0), 1048576: (1024000, 4600.0)}
+    for nominal, (n, side) in want.items():
+        a, L = pkg.scene_dambreak(nominal, fp64)
+        assert len(a["id"]) == n and L == side
+        if nominal <= 262144:
+            b, L2 = oracle.scene_dambreak(nominal, fp64)
+            assert L2 == side
+            for k in ("id", "mass", "pos", "vel", "colour"):
+                assert np.array_equal(a[k], b[k])
+        assert a["pos"].min() >= 100 and a["pos"].max() <= side - 100 + 1e-3
+        # grid extent = L/50 + 4 cells per axis stays within the 10-bit Morton range
+        assert side / 50 + 4 <= 1023
+
+
+@pytest.mark.parametrize("fp64", [False, True])
+def test_apply_motion_matches_golden(pkg, golden_dir, fp64):
+    G = np.load(os.path.join(golden_dir, "ref_grid.npz"))
+    base = pkg.default_params(4, 1000.0)
+    for f, want in zip(G["motion_frames"], G["motion_f64" if fp64 else "motion_f32"]):
+        p = pkg.apply_motion(base, int(f), fp64)
+        assert list(p.min_bound) == list(want[:3]) and list(p.max_bound) == list(want[3:])
+        assert p.dt == base.dt and p.iteration == 4
+
+
+def test_default_params_match_reference_config(pkg, golden_dir):
+    G = np.load(os.path.join(golden_dir, "ref_grid.npz"))
+    cfg = G["scene_2048_f64_cfg"]  # simpleConfigWith2Cubes(.., 4, 500) in double
+    p = pkg.default_params(4, 1000.0)
+    assert p.dt == cfg[0] and p.scale == cfg[1] and p.iteration == cfg[2]
+    assert list(p.constant_force) == list(cfg[3:6])
+    assert list(p.min_bound) == list(cfg[6:9]) and list(p.max_bound) == list(cfg[9:12])
+
+
+def test_fails_loudly_without_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.PbfError) as e:
+        pkg.Solver(h=0.1)
+    assert "no usable HIP device" in str(e.value) or "NO_DEVICE" in str(e.value) or "-3" in str(e.value)
+
+
+def test_create_rejects_bad_arguments(pkg):
+    from pbf_sph_amd import capi
+    L = pkg.lib()
+    ctx = C.c_void_p()
+    d = capi.Desc(99, 0, 0, 0, 0.1, None)
+    assert L.pbf_create(C.byref(d), C.byref(ctx)) == -1 and not ctx
+    d = capi.Desc(1, 0, 0, 0, -1.0, None)
+    assert L.pbf_create(C.byref(d), C.byref(ctx)) == -1
+    assert L.pbf_create(None, C.byref(ctx)) == -1
+    assert b"pbf_create" in L.pbf_last_error(None)
