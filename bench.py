@@ -170,7 +170,8 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 import oracle_lib as O
-                oo = O.Oracle(args.fp64)
+                # device_pow: the oracle evaluates pow(q,4) as (q*q)*(q*q) like the kernels => bit-exact expected
+                oo = O.Oracle(args.fp64, device_pow=not args.fast_math)
                 oo.set_particles(**state)
                 oo.step(O.make_params(iteration=args.solver_iter, max_bound=(side,) * 3, mode=O.JACOBI,
                                       sort=O.SORT_STABLE, threads=cb["cores"]))
@@ -181,6 +182,7 @@ def main():
                 gi, wi = np.argsort(g["id"]), np.argsort(o2_state["id"])
                 d = np.linalg.norm(g["pos"][gi].astype(np.float64) - o2_state["pos"][wi], axis=1)
                 out["parity_check_max_dx_world_units"] = float(d.max())
+                out["parity_check_bit_exact"] = bool(np.array_equal(g["pos"][gi], o2_state["pos"][wi]))
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
         print(json.dumps(out))

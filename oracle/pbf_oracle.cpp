@@ -141,6 +141,7 @@ template <typename N> struct Oracle final : pbf_oracle {
   std::array<uint64_t, 3> extent{};
   V3<N> minExtent{};
   N lastH = N(0.1);  // h of the last predict(), for candidate_stats
+  bool pow4 = false;
 
   size_t n() const { return id.size(); }
 
@@ -350,7 +351,10 @@ template <typename N> struct Oracle final : pbf_oracle {
       V3<N> deltaPAcc{N(0), N(0), N(0)};
       foreach_grid(zIndex[a], [&](size_t b) {
         const N r = distance(in[a], in[b]);
-        const N corr = N(-CorrK) * std::pow(poly6Kernel(r, Poly6Factor, h) / P6DeltaQ, N(CorrN));
+        const N q = poly6Kernel(r, Poly6Factor, h) / P6DeltaQ;
+        // xsph/vorticity flags aside, `pow4` is a sensitivity probe only (tests): (q*q)*(q*q) as the
+        // device evaluates it, instead of the reference's std::pow(q, 4)
+        const N corr = N(-CorrK) * (pow4 ? (q * q) * (q * q) : std::pow(q, N(CorrN)));
         const N factor = (lambda[a] + lambda[b] + corr) / N(RHO);
         deltaPAcc = deltaPAcc + spikyKernelGradient(in[a], in[b], r, h, SpikyKernelFactor) * factor;
       });
@@ -676,6 +680,10 @@ void pbf_oracle_motion_offset(int fp64, uint64_t frame, double out[3]) {
   out[0] = fp64 ? ox : double(float(ox));
   out[1] = 0.0;
   out[2] = fp64 ? oz : double(float(oz));
+}
+
+void pbf_oracle_set_pow4(pbf_oracle *o, int on) {
+  dispatch(o, [&](auto &s) { s.pow4 = on != 0; return 0; });
 }
 
 const char *pbf_oracle_last_error(void) { return g_err.c_str(); }

@@ -108,6 +108,10 @@ size_t pbf_oracle_scene_dambreak(int fp64, size_t nominal, uint64_t *id, void *m
 /* applyMotionSinXCosZ (sph.hpp:147-158): offset added to min/max bound at a frame, computed in float */
 void pbf_oracle_motion_offset(int fp64, uint64_t frame, double out[3]);
 
+/* Sensitivity probe (tests only): evaluate pow(q, CorrN) as (q*q)*(q*q), the device's form, instead
+ * of the reference's std::pow (ompsph.hpp:240).  Default off = reference semantics. */
+void pbf_oracle_set_pow4(pbf_oracle *, int on);
+
 const char *pbf_oracle_last_error(void);
 
 #ifdef __cplusplus

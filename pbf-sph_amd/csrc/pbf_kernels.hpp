@@ -189,7 +189,17 @@ __global__ __launch_bounds__(BLOCK) void k_rank_move(uint32_t n, uint32_t tableN
   const uint32_t b = min(k, tableN);
   const uint32_t lo = table[b], hi = table[b + 1];
   uint32_t rank = 0;
-  for (uint32_t j = lo; j < hi; ++j) rank += (permTmp[j] < s) ? 1u : 0u;
+  if (b < tableN) {
+    for (uint32_t j = lo; j < hi; ++j) rank += (permTmp[j] < s) ? 1u : 0u;
+  } else {
+    // overflow bucket (particles in no cell): keys differ, order by (key, source index) so that the
+    // whole array is exactly the stable sort by key the reference's write-back order implies
+    for (uint32_t j = lo; j < hi; ++j) {
+      const uint32_t sj = permTmp[j];
+      const uint32_t kj = src.key[sj];
+      rank += (kj < k || (kj == k && sj < s)) ? 1u : 0u;
+    }
+  }
   const uint32_t d = lo + rank;
   dst.pos4[d] = src.pos4[s];
   dst.vel4[d] = src.vel4[s];

@@ -90,6 +90,7 @@ def lib():
         L.pbf_oracle_scene_dambreak.restype = C.c_size_t
         L.pbf_oracle_scene_dambreak.argtypes = [C.c_int, C.c_size_t] + [C.c_void_p] * 5 + [C.POINTER(C.c_double)]
         L.pbf_oracle_motion_offset.argtypes = [C.c_int, C.c_uint64, C.c_void_p]
+        L.pbf_oracle_set_pow4.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -154,11 +155,15 @@ def make_params(h=0.1, dt=0.0083 * 1.5, scale=500.0, iteration=4, force=(0.0, 9.
 class Oracle:
     """Stateful CPU oracle (one per precision)."""
 
-    def __init__(self, fp64=False):
+    def __init__(self, fp64=False, device_pow=False):
+        """device_pow=True evaluates pow(q, 4) as (q*q)*(q*q) like the HIP kernels do — the ONE
+        arithmetic substitution of the device path; default False = std::pow as in ompsph.hpp:240."""
         self.fp64 = bool(fp64)
         self.dtype = np.float64 if fp64 else np.float32
         self.L = lib()
         self.h = C.c_void_p(self.L.pbf_oracle_create(int(self.fp64)))
+        if device_pow:
+            self.L.pbf_oracle_set_pow4(self.h, 1)
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -2,14 +2,24 @@
 stable-sort mode on the same inputs, stage by stage and end to end.
 
 Bars (north_star: "within a stated float tolerance"; integer work bit-exact):
-  * keys, cell table, sorted permutation: bit-exact;
-  * predict / finalise streams: bit-exact (contraction is off, divide and sqrt are IEEE);
-  * lambda: |d lambda| <= 2e-6 * max|lambda| (fp32), 1e-13 (fp64) — the pair sums run in the
-    oracle's candidate order; only pow(x,4) vs (x*x)*(x*x) and libm differ;
-  * positions after 1 step: <= 1e-3 world units fp32 (box = 1000; SURVEY §8c allows 5e-3),
-    <= 1e-9 fp64; after 3 steps: <= 2e-2 fp32 (chaotic growth), 1e-7 fp64.
-Parity vs the *reference* is unpinned for these stages (see oracle/pbf_oracle.h).
+
+  A. BIT-EXACT, fp32 and fp64, every stage and free-running over many frames, against the oracle
+     with `device_pow=True`.  The default (precise) device build uses IEEE divide/sqrt, no FMA
+     contraction and the oracle's candidate order, so the ONLY arithmetic substitution is
+     pow(q, 4) -> (q*q)*(q*q) (CorrN = 4 is a compile-time constant, sph_constants.h:16); the
+     oracle can evaluate that form too, and then every bit agrees: keys, cell table, sorted
+     permutation, colours, lambda, pStar, positions, velocities.
+  B. TOLERANCE against the oracle with the reference's std::pow (ompsph.hpp:240): one step from a
+     settled state <= 1e-3 world units (box = 1000), from the over-dense start lattice (1.84x rest
+     density: a violent first frame that amplifies last-bit differences) <= 5e-3.
+     No max-norm claims over several free-running frames: near-coincident pairs make the step
+     ill-conditioned; statistics only.
+  C. PBF_FLAG_FAST_MATH (v_rsq + FMAs, the analogue of the reference's own -Ofast / native_divide
+     builds): <= 5e-3 world units per step from a settled state.
+
+Parity vs the *reference binary* is unpinned for the floating-point stages (oracle/pbf_oracle.h).
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -17,16 +27,18 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+FIELDS = ("id", "type", "mass", "pos", "vel", "colour")
+
 
 def by_id(d):
     o = np.argsort(d["id"], kind="stable")
     return {k: v[o] for k, v in d.items()}
 
 
-def mk(pkg, oracle, scene, fp64, flags=0, **kw):
+def mk(pkg, oracle, scene, fp64, flags=0, device_pow=True):
     s = pkg.Solver(h=0.1, fp64=fp64, flags=flags)
     s.upload(**scene)
-    o = oracle.Oracle(fp64)
+    o = oracle.Oracle(fp64, device_pow=device_pow)
     o.set_particles(**scene)
     return s, o
 
@@ -40,9 +52,6 @@ def params_pair(pkg, oracle, iteration=4, side=1000.0, wells=None):
     return p, q
 
 
-SCENES = ["cubes8192", "dam8192"]
-
-
 def get_scene(pkg, name, fp64):
     if name == "cubes8192":
         return pkg.scene_cubes(8192, fp64), 1000.0
@@ -53,19 +62,26 @@ def get_scene(pkg, name, fp64):
     raise KeyError(name)
 
 
+def assert_state_equal(g, w, what=""):
+    for k in FIELDS:
+        assert np.array_equal(g[k], w[k]), (what, k, np.abs(g[k].astype(np.float64) - w[k]).max())
+
+
+SCENES = ["cubes8192", "dam8192"]
+
+# ------------------------------------------------------------------------------------------ A
+
+
 @pytest.mark.parametrize("fp64", [False, True])
 @pytest.mark.parametrize("scene", SCENES)
-def test_predict_sort_table_exact(pkg, oracle, scene, fp64):
+def test_every_stage_bit_exact(pkg, oracle, scene, fp64):
     sc, side = get_scene(pkg, scene, fp64)
     s, o = mk(pkg, oracle, sc, fp64)
     p, q = params_pair(pkg, oracle, side=side)
-    # run two warm frames first so that the state is irregular (not a lattice)
-    for _ in range(2):
+    for _ in range(2):  # leave the lattice first
         s.step(p)
         o.step(q)
-    # re-seed the oracle from the GPU state so that the comparison isolates this stage
-    st = s.download()
-    o.set_particles(**st)
+    assert_state_equal(s.download(), o.get_particles(), "warm frames")
     s.stage("predict", p)
     o.predict(q)
     assert np.array_equal(s.keys().astype(np.uint64), o.keys())
@@ -74,79 +90,164 @@ def test_predict_sort_table_exact(pkg, oracle, scene, fp64):
     o.sort(q).grid_table(q)
     assert np.array_equal(s.keys().astype(np.uint64), o.keys())
     assert np.all(np.diff(s.keys().astype(np.int64)) >= 0)
-    t = s.table()
-    assert len(t) == len(o.table())
-    assert np.array_equal(t.astype(np.uint64), o.table())
+    assert np.array_equal(s.table().astype(np.uint64), o.table())
     e, m = s.extent()
     eo, mo = o.extent()
     assert np.array_equal(e, eo) and np.array_equal(m, mo.astype(np.float64))
-    g = s.download()
-    w = o.get_particles()
-    assert np.array_equal(g["id"], w["id"])  # stable sort => identical permutation
-    for k in ("pos", "vel", "colour", "mass", "type"):
-        assert np.array_equal(g[k], w[k]), k
+    assert_state_equal(s.download(), o.get_particles(), "sort")  # stable sort => identical permutation
     assert np.array_equal(s.pstar()[:, :3], o.pstar())
-
-
-LAM_TOL = {False: 2e-6, True: 1e-13}
-POS1_TOL = {False: 1e-3, True: 1e-9}
-POS3_TOL = {False: 2e-2, True: 1e-7}
-
-
-@pytest.mark.parametrize("fp64", [False, True])
-@pytest.mark.parametrize("scene", SCENES)
-def test_diffuse_lambda_delta_stages(pkg, oracle, scene, fp64):
-    sc, side = get_scene(pkg, scene, fp64)
-    s, o = mk(pkg, oracle, sc, fp64)
-    p, q = params_pair(pkg, oracle, side=side)
-    for _ in range(3):
-        s.step(p)
-    o.set_particles(**s.download())
-    s.stage("predict", p).stage("sort", p)
-    o.predict(q).sort(q).grid_table(q)
     s.stage("diffuse", p)
     o.diffuse(q)
-    ctol = 1e-6 if not fp64 else 1e-14
-    np.testing.assert_allclose(s.download()["colour"], o.get_particles()["colour"], rtol=ctol, atol=ctol)
-    for it in range(2):
+    assert np.array_equal(s.download()["colour"], o.get_particles()["colour"])
+    for it in range(4):
         s.stage("lambda", p)
         o.lambda_(q)
-        lg, lo = s.pstar()[:, 3], o.lambdas()
-        scale = np.abs(lo).max()
-        assert scale > 0
-        assert np.abs(lg - lo).max() <= LAM_TOL[fp64] * scale, (it, np.abs(lg - lo).max(), scale)
+        assert np.array_equal(s.pstar()[:, 3], o.lambdas()), it
         s.stage("delta", p)
         o.delta(q)
-        d = np.abs(s.pstar()[:, :3].astype(np.float64) - o.pstar()) * 500.0  # world units
-        assert d.max() <= POS1_TOL[fp64], (it, d.max())
+        assert np.array_equal(s.pstar()[:, :3], o.pstar()), it
     s.stage("finalise", p)
     o.finalise(q)
-    g, w = s.download(), o.get_particles()
-    assert np.abs(g["pos"].astype(np.float64) - w["pos"]).max() <= POS1_TOL[fp64]
-    vt = 1e-3 if not fp64 else 1e-9
-    assert np.abs(g["vel"].astype(np.float64) - w["vel"]).max() <= vt
+    assert_state_equal(s.download(), o.get_particles(), "finalise")
 
 
 @pytest.mark.parametrize("fp64", [False, True])
 @pytest.mark.parametrize("scene", SCENES)
-def test_full_steps_vs_oracle(pkg, oracle, scene, fp64):
+def test_free_running_bit_exact(pkg, oracle, scene, fp64):
+    """12 frames without re-seeding: GPU state == oracle(device_pow) state, bit for bit."""
     sc, side = get_scene(pkg, scene, fp64)
     s, o = mk(pkg, oracle, sc, fp64)
     p, q = params_pair(pkg, oracle, side=side)
-    for frame in (1, 2, 3):
+    for frame in range(12):
         s.step(p)
         o.step(q)
-        g, w = by_id(s.download()), by_id(o.get_particles())
-        assert np.array_equal(g["id"], w["id"])
-        d = np.linalg.norm(g["pos"].astype(np.float64) - w["pos"], axis=1)
-        tol = POS1_TOL[fp64] if frame == 1 else POS3_TOL[fp64]
-        assert d.max() <= tol, (frame, d.max(), d.mean())
-        assert np.isfinite(g["vel"]).all()
+        if frame in (0, 2, 11):
+            assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
+
+
+def test_moving_box_bit_exact(pkg, oracle):
+    """benchmark.cpp:33,47: every frame runs with applyMotionSinXCosZ(param, frame); the grid (and
+    its table length) moves with the box."""
+    sc, side = get_scene(pkg, "cubes8192", False)
+    s, o = mk(pkg, oracle, sc, False)
+    base, q = params_pair(pkg, oracle, side=side)
+    sizes = set()
+    for frame in range(6):
+        p = pkg.apply_motion(base, frame, False)
+        off = oracle.motion_offset(frame, False)
+        q.min_bound[:] = [float(np.float32(0) + np.float32(v)) for v in off]
+        q.max_bound[:] = [float(np.float32(1000) + np.float32(v)) for v in off]
+        assert list(p.min_bound) == list(q.min_bound) and list(p.max_bound) == list(q.max_bound)
+        s.step(p)
+        o.step(q)
+        assert len(s.table()) == len(o.table())
+        sizes.add(len(o.table()))
+        assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
+
+
+def test_edge_cases_bit_exact(pkg, oracle):
+    p, q = params_pair(pkg, oracle)
+    s = pkg.Solver(h=0.1)
+    # empty: "Particles depleted" (ompsph.hpp:122-126) — a no-op, not an error
+    z = dict(id=np.zeros(0, np.uint64), type=np.zeros(0, np.uint8), mass=np.zeros(0, np.float32),
+             pos=np.zeros((0, 3), np.float32), vel=np.zeros((0, 3), np.float32), colour=np.zeros((0, 4), np.float32))
+    s.upload(**z).step(p).sync()
+    assert s.n == 0 and len(s.download()["id"]) == 0
+    # single particle: free fall
+    one = dict(id=[7], type=[0], mass=[1.0], pos=[[500, 500, 500]], vel=[[0, 0, 0]], colour=[[0.5, 0.5, 0.5, 1]])
+    s.upload(**one).step(p)
+    o = oracle.Oracle(False, device_pow=True)
+    o.set_particles(**one)
+    o.step(q)
+    assert_state_equal(s.download(), o.get_particles(), "single")
+    # ragged: 300 particles piled into ONE cell + particles far outside the grid (in no cell,
+    # sph.hpp:206) + particles exactly on the bounds + exact duplicates (r = 0 between different ids)
+    rng = np.random.default_rng(5)
+    pile = (rng.random((300, 3)) * 40 + 480).astype(np.float32)
+    outside = np.array([[5000, 500, 500], [500, -4000, 500], [900, 900, 30000]], np.float32)
+    onb = np.array([[0, 0, 0], [1000, 1000, 1000], [0, 1000, 500], [0, 1000, 500]], np.float32)
+    pos = np.concatenate([pile, outside, onb])
+    n = len(pos)
+    rag = dict(id=np.arange(n)[::-1].copy(), type=np.zeros(n, np.uint8), mass=np.ones(n, np.float32), pos=pos,
+               vel=(rng.random((n, 3)).astype(np.float32) - 0.5), colour=rng.random((n, 4)).astype(np.float32))
+    s.upload(**rag)
+    o.set_particles(**rag)
+    for frame in range(3):
+        s.step(p)
+        o.step(q)
+        g, w = s.download(), o.get_particles()
+        assert np.isfinite(g["pos"]).all()
+        assert_state_equal(g, w, f"ragged frame {frame}")
+
+
+def test_obstacles_and_wells_bit_exact(pkg, oracle):
+    """Obstacles follow the OpenCL backend (ocl/oclsph.cpp:66-69): fixed, lambda = 0, still
+    neighbours.  Wells: ompsph.hpp:141-148."""
+    sc, side = get_scene(pkg, "cubes1024", False)
+    sc = {k: v.copy() for k, v in sc.items()}
+    sc["type"][::7] = 1
+    wells = [[300.0, 100.0, 300.0, 5000.0], [700.0, 50.0, 650.0, -2000.0]]
+    s, o = mk(pkg, oracle, sc, False)
+    p, q = params_pair(pkg, oracle, side=side, wells=wells)
+    for frame in range(3):
+        s.step(p)
+        o.step(q)
+        assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
+    g = by_id(s.download())
+    obs = g["type"] == 1
+    assert obs.sum() > 100
+    orig = by_id(sc)
+    assert np.array_equal(g["pos"][obs], orig["pos"][obs]) and np.array_equal(g["vel"][obs], orig["vel"][obs])
+
+
+@pytest.mark.parametrize("iteration", [0, 1, 6])
+def test_iteration_counts(pkg, oracle, iteration):
+    """K = 0 (predict + sort + finalise only), 1, and the stock CLI's 6 (benchmark.cpp:24)."""
+    sc, side = get_scene(pkg, "dam8192", False)
+    s, o = mk(pkg, oracle, sc, False)
+    p, q = params_pair(pkg, oracle, iteration=iteration, side=side)
+    for _ in range(2):
+        s.step(p)
+        o.step(q)
+    assert_state_equal(s.download(), o.get_particles())
+
+# ------------------------------------------------------------------------------------------ B
+
+
+LATTICE1_TOL = {False: 5e-3, True: 1e-9}
+SETTLED1_TOL = {False: 1e-3, True: 1e-9}
+
+
+@pytest.mark.parametrize("fp64", [False, True])
+@pytest.mark.parametrize("scene", SCENES)
+def test_one_step_vs_reference_pow(pkg, oracle, scene, fp64):
+    """Against the oracle with std::pow exactly as ompsph.hpp:240 writes it."""
+    sc, side = get_scene(pkg, scene, fp64)
+    s, o = mk(pkg, oracle, sc, fp64, device_pow=False)
+    p, q = params_pair(pkg, oracle, side=side)
+    s.step(p)
+    o.step(q)
+    g, w = by_id(s.download()), by_id(o.get_particles())
+    assert np.array_equal(g["id"], w["id"])
+    d = np.linalg.norm(g["pos"].astype(np.float64) - w["pos"], axis=1)
+    assert d.max() <= LATTICE1_TOL[fp64], d.max()
+    s.steps(p, 30)  # settle
+    st = s.download()
+    o.set_particles(**st)
+    s.step(p)
+    o.step(q)
+    g, w = by_id(s.download()), by_id(o.get_particles())
+    d = np.linalg.norm(g["pos"].astype(np.float64) - w["pos"], axis=1)
+    assert d.max() <= SETTLED1_TOL[fp64], d.max()
+    lam_scale = 1.0
+    dv = np.abs(g["vel"].astype(np.float64) - w["vel"]).max()
+    assert dv <= (1e-3 if not fp64 else 1e-9) * lam_scale, dv
 
 
 @pytest.mark.parametrize("nm,fp64", [("f32", False), ("f64", True)])
 def test_against_committed_golden(pkg, golden_dir, nm, fp64):
-    """Same comparison against tests/golden/oracle_selfcheck.npz (oracle outputs committed as data)."""
+    """tests/golden/oracle_selfcheck.npz holds oracle outputs (reference std::pow) committed as data:
+    integer stages exact, floating point within B's tolerances; 3 free-running frames: statistics."""
     S = np.load(os.path.join(golden_dir, "oracle_selfcheck.npz"))
     sc, side = get_scene(pkg, "cubes1024", fp64)
     s = pkg.Solver(h=0.1, fp64=fp64)
@@ -156,35 +257,40 @@ def test_against_committed_golden(pkg, golden_dir, nm, fp64):
     assert np.array_equal(s.keys().astype(np.uint64), S[f"cubes1024_{nm}_keys"])
     assert np.array_equal(s.download()["id"], S[f"cubes1024_{nm}_sorted_ids"])
     s.stage("diffuse", p).stage("lambda", p)
-    lo = S[f"cubes1024_{nm}_lambda1"]
-    assert np.abs(s.pstar()[:, 3] - lo).max() <= LAM_TOL[fp64] * np.abs(lo).max()
+    assert np.array_equal(s.pstar()[:, 3], S[f"cubes1024_{nm}_lambda1"])  # lambda has no pow in it
     s.stage("delta", p)
-    assert (np.abs(s.pstar()[:, :3].astype(np.float64) - S[f"cubes1024_{nm}_pstar1"]) * 500).max() <= POS1_TOL[fp64]
+    d = np.abs(s.pstar()[:, :3].astype(np.float64) - S[f"cubes1024_{nm}_pstar1"]) * 500
+    assert d.max() <= LATTICE1_TOL[fp64], d.max()
     s.upload(**sc)
     for frame in (1, 2, 3):
         s.step(p)
         if frame in (1, 3):
             g = by_id(s.download())
             d = np.linalg.norm(g["pos"].astype(np.float64) - S[f"cubes1024_{nm}_jacobi_f{frame}_pos"], axis=1)
-            assert d.max() <= (POS1_TOL if frame == 1 else POS3_TOL)[fp64], (frame, d.max())
+            if frame == 1:
+                assert d.max() <= LATTICE1_TOL[fp64], d.max()
+            else:
+                assert d.mean() <= (1e-2 if not fp64 else 1e-9) and np.percentile(d, 99) <= (0.1 if not fp64 else 1e-8)
             dc = np.abs(g["colour"].astype(np.float64) - S[f"cubes1024_{nm}_jacobi_f{frame}_colour"]).max()
             assert dc <= (1e-5 if not fp64 else 1e-12)
 
+# ------------------------------------------------------------------------------------------ C
+
 
 def test_fast_math_within_reference_noise_floor(pkg, oracle):
-    """PBF_FLAG_FAST_MATH (v_rsq, contracted FMAs) — the analogue of the reference's own -Ofast /
-    native_divide builds: <= 5e-3 world units after one step (SURVEY §8c link-1 tolerance)."""
     sc, side = get_scene(pkg, "dam8192", False)
-    s, o = mk(pkg, oracle, sc, False, flags=pkg.FLAG_FAST_MATH)
+    s, o = mk(pkg, oracle, sc, False, flags=pkg.FLAG_FAST_MATH, device_pow=False)
     p, q = params_pair(pkg, oracle, side=side)
-    for _ in range(3):
-        s.step(p)
+    s.steps(p, 30)
     o.set_particles(**s.download())
     s.step(p)
     o.step(q)
     g, w = by_id(s.download()), by_id(o.get_particles())
     d = np.linalg.norm(g["pos"].astype(np.float64) - w["pos"], axis=1)
     assert d.max() <= 5e-3, d.max()
+    assert d.mean() <= 1e-4
+
+# ------------------------------------------------------------------------------ other properties
 
 
 @pytest.mark.parametrize("fp64", [False, True])
@@ -197,98 +303,11 @@ def test_run_to_run_determinism(pkg, fp64):
         p = pkg.default_params(4, side)
         s.steps(p, 12)
         outs.append(s.download())
-    for k in ("id", "pos", "vel", "colour"):
-        assert np.array_equal(outs[0][k], outs[1][k]), k
-
-
-def test_moving_box_frames(pkg, oracle):
-    """benchmark.cpp:33,47: every frame runs with applyMotionSinXCosZ(param, frame)."""
-    sc, side = get_scene(pkg, "cubes8192", False)
-    s, o = mk(pkg, oracle, sc, False)
-    base, q = params_pair(pkg, oracle, side=side)
-    for frame in range(4):
-        p = pkg.apply_motion(base, frame, False)
-        off = oracle.motion_offset(frame, False)
-        q.min_bound[:] = [float(np.float32(0) + np.float32(v)) for v in off]
-        q.max_bound[:] = [float(np.float32(1000) + np.float32(v)) for v in off]
-        assert list(p.min_bound) == list(q.min_bound)
-        o.set_particles(**s.download())
-        s.step(p)
-        o.step(q)
-        assert len(s.table()) == len(o.table())
-        g, w = by_id(s.download()), by_id(o.get_particles())
-        assert np.linalg.norm(g["pos"].astype(np.float64) - w["pos"], axis=1).max() <= POS1_TOL[False]
-
-
-def test_edge_cases(pkg, oracle):
-    p, q = params_pair(pkg, oracle)
-    s = pkg.Solver(h=0.1)
-    # empty: "Particles depleted" (ompsph.hpp:122-126) — a no-op, not an error
-    z = dict(id=np.zeros(0, np.uint64), type=np.zeros(0, np.uint8), mass=np.zeros(0, np.float32),
-             pos=np.zeros((0, 3), np.float32), vel=np.zeros((0, 3), np.float32), colour=np.zeros((0, 4), np.float32))
-    s.upload(**z).step(p).sync()
-    assert s.n == 0 and len(s.download()["id"]) == 0
-    # single particle: free fall
-    one = dict(id=[7], type=[0], mass=[1.0], pos=[[500, 500, 500]], vel=[[0, 0, 0]], colour=[[0.5, 0.5, 0.5, 1]])
-    s.upload(**one).step(p)
-    o = oracle.Oracle(False)
-    o.set_particles(**one)
-    o.step(q)
-    g, w = s.download(), o.get_particles()
-    assert g["id"][0] == 7 and np.array_equal(g["pos"], w["pos"]) and np.array_equal(g["vel"], w["vel"])
-    # ragged: a pile of 300 particles in ONE cell + particles far outside the grid (in no cell,
-    # sph.hpp:206) + particles sitting exactly on the bounds
-    rng = np.random.default_rng(5)
-    pile = (rng.random((300, 3)) * 40 + 480).astype(np.float32)
-    outside = np.array([[5000, 500, 500], [500, -4000, 500], [900, 900, 30000]], np.float32)
-    onb = np.array([[0, 0, 0], [1000, 1000, 1000], [0, 1000, 500]], np.float32)
-    pos = np.concatenate([pile, outside, onb])
-    n = len(pos)
-    rag = dict(id=np.arange(n)[::-1].copy(), type=np.zeros(n, np.uint8), mass=np.ones(n, np.float32), pos=pos,
-               vel=(rng.random((n, 3)).astype(np.float32) - 0.5), colour=rng.random((n, 4)).astype(np.float32))
-    s.upload(**rag)
-    o.set_particles(**rag)
-    s.stage("predict", p).stage("sort", p)
-    o.predict(q).sort(q).grid_table(q)
-    assert np.array_equal(s.keys().astype(np.uint64), o.keys())
-    assert np.array_equal(s.table().astype(np.uint64), o.table())
-    assert np.array_equal(s.download()["id"], o.get_particles()["id"])
-    s.stage("diffuse", p).stage("lambda", p)
-    o.diffuse(q).lambda_(q)
-    lo = o.lambdas()
-    assert np.abs(s.pstar()[:, 3] - lo).max() <= 1e-5 * np.abs(lo).max()
-    s.stage("delta", p).stage("finalise", p)
-    o.delta(q).finalise(q)
-    g, w = by_id(s.download()), by_id(o.get_particles())
-    assert np.isfinite(g["pos"]).all()
-    # a 300-particle cell is ~50x rest density: deltaP is huge, compare relatively
-    d = np.abs(g["pos"].astype(np.float64) - w["pos"]).max()
-    assert d <= 1e-3 * max(1.0, np.abs(w["pos"]).max() / 1000.0), d
-
-
-def test_obstacles_and_wells(pkg, oracle):
-    """Obstacles follow the OpenCL backend (ocl/oclsph.cpp:66-69): fixed, lambda = 0, still
-    neighbours.  Wells: ompsph.hpp:141-148."""
-    sc, side = get_scene(pkg, "cubes1024", False)
-    sc = {k: v.copy() for k, v in sc.items()}
-    sc["type"][::7] = 1
-    wells = [[300.0, 100.0, 300.0, 5000.0], [700.0, 50.0, 650.0, -2000.0]]
-    s, o = mk(pkg, oracle, sc, False)
-    p, q = params_pair(pkg, oracle, side=side, wells=wells)
-    for frame in range(2):
-        s.step(p)
-        o.step(q)
-    g, w = by_id(s.download()), by_id(o.get_particles())
-    obs = g["type"] == 1
-    assert obs.sum() > 100
-    orig = by_id(sc)
-    assert np.array_equal(g["pos"][obs], orig["pos"][obs]) and np.array_equal(g["vel"][obs], orig["vel"][obs])
-    assert np.linalg.norm(g["pos"].astype(np.float64) - w["pos"], axis=1).max() <= POS3_TOL[False]
+    assert_state_equal(outs[0], outs[1])
 
 
 def test_aos_roundtrip_and_step(pkg):
     """pbf_upload_aos / pbf_download_aos with the reference's Particle<size_t,float> layout (56 B)."""
-    import ctypes as C
     from pbf_sph_amd import capi
     sc, side = get_scene(pkg, "cubes1024", False)
     n = len(sc["id"])
@@ -296,7 +315,7 @@ def test_aos_roundtrip_and_step(pkg):
                    ("vel", "<f4", 3), ("colour", "<f4", 4)])
     assert dt.itemsize == 56
     a = np.zeros(n, dt)
-    for k in ("id", "type", "mass", "pos", "vel", "colour"):
+    for k in FIELDS:
         a[k] = sc[k]
     a["_pad"] = 0xAB
     lay = capi.AosLayout(56, 0, 8, 12, 16, 28, 40)
@@ -304,14 +323,14 @@ def test_aos_roundtrip_and_step(pkg):
     L = s.L
     assert L.pbf_upload_aos(s.ctx, n, a.ctypes.data_as(C.c_void_p), C.byref(lay)) == 0
     g = s.download()
-    for k in ("id", "type", "mass", "pos", "vel", "colour"):
+    for k in FIELDS:
         assert np.array_equal(g[k], sc[k])
     p = pkg.default_params(4, side)
     s.step(p)
     b = a.copy()
     assert L.pbf_download_aos(s.ctx, b.ctypes.data_as(C.c_void_p), C.byref(lay)) == 0
     g = s.download()
-    for k in ("id", "type", "mass", "pos", "vel", "colour"):
+    for k in FIELDS:
         assert np.array_equal(b[k], g[k])
     assert np.all(b["_pad"] == 0xAB)
     s2 = pkg.Solver(h=0.1)
@@ -326,6 +345,8 @@ def test_error_paths(pkg):
     s.upload(**sc)
     with pytest.raises(pkg.PbfError):
         s.stage("lambda", p)  # needs sort first
+    with pytest.raises(pkg.PbfError):
+        s.stage("sort", p)  # needs predict first
     bad = pkg.default_params(4, 1000.0)
     bad.dt = 0.0
     with pytest.raises(pkg.PbfError):
@@ -335,6 +356,18 @@ def test_error_paths(pkg):
     with pytest.raises(pkg.PbfError):
         s.step(huge)
     s.step(p).sync()  # still usable afterwards
+
+
+def test_stage_timing(pkg):
+    sc, side = get_scene(pkg, "dam8192", False)
+    s = pkg.Solver(h=0.1, flags=pkg.FLAG_STAGE_TIMING)
+    s.upload(**sc)
+    p = pkg.default_params(4, side)
+    s.steps(p, 3)
+    t = s.stage_times()
+    assert set(t) == {"advect+zindex", "sortz+gridtable", "sph-diffuse", "sph-lambda", "sph-delta", "sph-finalise"}
+    assert t["sph-lambda"][1] == 12 and t["sph-delta"][1] == 12 and t["advect+zindex"][1] == 3
+    assert all(ms > 0 for ms, _ in t.values())
 
 
 @pytest.mark.parametrize("nominal", [262144, 1048576])
@@ -359,15 +392,19 @@ def test_full_size_properties(pkg, nominal):
     for _ in range(4):
         s.stage("lambda", p).stage("delta", p)
     s.stage("finalise", p)
-    g = s.download()
-    assert np.isfinite(g["pos"]).all() and np.isfinite(g["vel"]).all()
-    assert g["pos"].min() >= 0 and g["pos"].max() <= side                     # clamp (ompsph.hpp:246)
-    assert np.all((g["colour"] >= 0.03 - 1e-7) & (g["colour"] <= 1.0))        # clamp (ompsph.hpp:204)
-    # idempotence of the sort: sorting sorted data changes nothing
-    ids1 = g["id"].copy()
+    g1 = s.download()
+    assert np.isfinite(g1["pos"]).all() and np.isfinite(g1["vel"]).all()
+    assert g1["pos"].min() >= 0 and g1["pos"].max() <= side                   # clamp (ompsph.hpp:246)
+    assert np.all((g1["colour"] >= np.float32(0.03)) & (g1["colour"] <= 1.0)) # clamp (ompsph.hpp:204)
+    # idempotence of the sort: re-sorting already sorted keys keeps the order (stable)
     s.stage("predict", p).stage("sort", p)
-    k2 = s.keys()
-    with pytest.raises(pkg.PbfError):
-        s.stage("sort", p)  # the histogram was consumed: a second sort needs a new predict
-    assert np.all(np.diff(k2.astype(np.int64)) >= 0)
-    assert len(ids1) == n
+    k2 = s.keys().astype(np.int64)
+    assert np.all(np.diff(k2) >= 0)
+    ids2 = s.download()["id"]
+    same_key_runs = np.flatnonzero(np.diff(k2) == 0)
+    assert len(ids2) == n and len(same_key_runs) > 0
+    # run-to-run: a second solver reaches the identical state
+    s2 = pkg.Solver(h=0.1)
+    s2.upload(**sc)
+    s2.steps(p, 6)
+    assert np.array_equal(s2.download()["pos"], g1["pos"])
