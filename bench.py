@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--fp64", action="store_true")
     ap.add_argument("--fast-math", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lds", action="store_true", help="A/B: per-particle global-memory gather kernels")
     args = ap.parse_args()
 
     import torch
@@ -97,7 +98,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = load_package()
-    flags = pkg.FLAG_STAGE_TIMING | (pkg.FLAG_FAST_MATH if args.fast_math else 0)
+    flags = pkg.FLAG_STAGE_TIMING | (pkg.FLAG_FAST_MATH if args.fast_math else 0) | (pkg.FLAG_NO_LDS if args.no_lds else 0)
     scene, side = pkg.scene_dambreak(args.particles, args.fp64)
     n = len(scene["id"])
     solver = pkg.Solver(h=0.1, fp64=args.fp64, device=local_rank, flags=flags)

@@ -78,6 +78,10 @@ void pbf_destroy(pbf_ctx *ctx);
 /* ctx may be NULL: last error of a failed pbf_create on this thread */
 const char *pbf_last_error(const pbf_ctx *ctx);
 int pbf_abi_version(void);
+/* Tuning / diagnostic knobs (no reference counterpart): "gather" (0 global walk, 1 filtered lists, 2 LDS bricks),
+ * "list_max", "tile_cap", "probe".
+ * Unknown names return PBF_ERR_INVALID. */
+int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value);
 
 /* ---- particle state (replaces the std::vector<Particle>& in/out argument, src/sph.hpp:124) */
 int pbf_upload(pbf_ctx *ctx, size_t n, const uint64_t *id, const uint8_t *type, const void *mass, const void *pos,

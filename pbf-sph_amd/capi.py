@@ -81,6 +81,7 @@ _lib = None
 
 _SIGS = {
     "pbf_abi_version": (C.c_int, []),
+    "pbf_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "pbf_create": (C.c_int, [C.POINTER(Desc), C.POINTER(C.c_void_p)]),
     "pbf_destroy": (None, [C.c_void_p]),
     "pbf_last_error": (C.c_char_p, [C.c_void_p]),
@@ -235,6 +236,10 @@ class Solver:
 
     def steps(self, p, count):
         self._chk(self.L.pbf_steps(self.ctx, C.byref(p), count), "pbf_steps")
+        return self
+
+    def set_option(self, name, value):
+        self._chk(self.L.pbf_set_option(self.ctx, name.encode(), int(value)), "pbf_set_option")
         return self
 
     def sync(self):

@@ -71,10 +71,12 @@ template <typename N> struct StepConsts {
   N minExtent[3];
   N poly6Factor, spikyFactor, p6DeltaQ;
   N diffuseT;  // dt / 750 (ompsph.hpp:203)
+  N h2filter;  // h^2 (1 + 1e-5): conservative candidate filter, see maybe_within_h
   uint32_t n;
   uint32_t tableN;  // Morton(extent) (sph.hpp:240)
   uint32_t nWells;
   uint32_t hasObstacles;
+  uint32_t probe;  // diagnostics only (env PBF_PROBE): 1 = loads without pair math, 2 = pair math without loads
 };
 
 }  // namespace pbf

@@ -8,7 +8,9 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -25,6 +27,9 @@ struct DevBuf {
   size_t cap = 0;
   template <typename T> T *as() const { return static_cast<T *>(p); }
 };
+
+constexpr uint32_t kTickets = 255;
+constexpr int kBrickZ = 4;
 
 enum Stage { ST_PREDICT = 0, ST_SORT, ST_DIFFUSE, ST_LAMBDA, ST_DELTA, ST_FINALISE, ST_COUNT };
 // names follow the reference's Stopwatch entries (ompsph.hpp:130,157,161,188,209,252)
@@ -58,6 +63,12 @@ struct pbf_ctx {
   DevBuf pos4[2], vel4[2], col4[2], id[2], type[2], key[2];
   DevBuf pstar[3];       // [0],[1]: sort ping-pong partner of set 0/1 ; [2]: Jacobi partner
   DevBuf count, table, blockSums, permTmp, wells, staging;
+  DevBuf bricks, brickCtl;  // non-empty brick list; brickCtl = {nActive, ticket[kTickets]}
+  uint32_t gatherSeq = 0;   // which ticket word the next persistent gather launch uses
+  int numCUs = 256;
+  uint32_t probe = 0;       // env PBF_PROBE (diagnostics, see StepConsts::probe)
+  int gatherKind = 0;       // 0 = global walk (k_gather_global), 1 = filtered lists, 2 = persistent LDS bricks
+  uint32_t tileCap = 0, listMax = 0;  // 0 = defaults (env PBF_TILE_CAP / PBF_LIST_MAX override)
   size_t tableCap = 0;   // entries allocated in count/table
   uint32_t tableN = 0;
   uint32_t countedTableN = 0;
@@ -172,9 +183,11 @@ template <typename N> int make_consts(pbf_ctx *ctx, const pbf_params *p, StepCon
     c.p6DeltaQ = r <= h ? c.poly6Factor * (d * d * d) : N(0);
   }
   c.diffuseT = c.dt / N(750.0);
+  c.h2filter = (h * h) * N(1.00001);
   c.n = uint32_t(ctx->n);
   c.nWells = uint32_t(p->n_wells > 0 ? p->n_wells : 0);
   c.hasObstacles = ctx->hasObstacles ? 1u : 0u;
+  c.probe = ctx->probe;
   ctx->tableN = c.tableN;
   return PBF_OK;
 }
@@ -200,6 +213,8 @@ int ensure_table(pbf_ctx *ctx, uint32_t tableN) {
   if (int rc = ensure(ctx, ctx->table, (entries + SCAN_TILE) * 4)) return rc;
   const size_t nb = (entries + SCAN_TILE - 1) / SCAN_TILE + 1;
   if (int rc = ensure(ctx, ctx->blockSums, nb * 4)) return rc;
+  if (int rc = ensure(ctx, ctx->bricks, (entries / Brick<kBrickZ>::HOME + 2) * 4)) return rc;
+  if (int rc = ensure(ctx, ctx->brickCtl, (kTickets + 1) * 4)) return rc;
   ctx->tableCap = ctx->count.cap / 4 - SCAN_TILE;
   return PBF_OK;
 }
@@ -315,6 +330,13 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
                      ctx->key[s].as<const uint32_t>(), table, count, ctx->permTmp.as<uint32_t>());
   hipLaunchKernelGGL((k_rank_move<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c.n, c.tableN,
                      ctx->permTmp.as<const uint32_t>(), table, arrays<N>(ctx, s, s), arrays<N>(ctx, d, d));
+  {  // list of non-empty bricks for the persistent gather kernels (+ fresh tickets)
+    const uint32_t home = Brick<kBrickZ>::HOME, nBricks = (c.tableN + home - 1) / home;
+    HIPCHK(ctx, hipMemsetAsync(ctx->brickCtl.p, 0, (kTickets + 1) * 4, ctx->stream));
+    hipLaunchKernelGGL(k_brick_list, grid_for(nBricks), dim3(BLOCK), 0, ctx->stream, table, c.tableN, home, nBricks,
+                       ctx->bricks.as<uint32_t>(), ctx->brickCtl.as<uint32_t>());
+    ctx->gatherSeq = 0;
+  }
   LAUNCH_CHECK(ctx);
   ctx->cur = d;
   ctx->pcur = d;
@@ -326,15 +348,64 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
 // the Jacobi partner of pstar[pcur]: any of the three buffers that is neither live nor needed
 inline int other_pstar(const pbf_ctx *ctx) { return ctx->pcur == 2 ? ctx->cur : 2; }
 
+// Launch one gather stage.  gatherKind picks the kernel (option "gather" / env PBF_GATHER);
+// PBF_FLAG_NO_LDS always forces the plain per-particle global walk.
+template <typename N, typename Op> int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args) {
+  const uint32_t *key = ctx->key[ctx->cur].as<const uint32_t>();
+  const uint32_t *table = ctx->table.as<const uint32_t>();
+  if ((ctx->desc.flags & PBF_FLAG_NO_LDS) || ctx->gatherKind == 0) {
+    hipLaunchKernelGGL((k_gather_global<N, Op>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table);
+    LAUNCH_CHECK(ctx);
+    return PBF_OK;
+  }
+  if (ctx->gatherKind == 1) {
+    switch (ctx->listMax ? ctx->listMax : 32u) {
+      case 16: hipLaunchKernelGGL((k_gather_lists<N, Op, 16>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
+      case 24: hipLaunchKernelGGL((k_gather_lists<N, Op, 24>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
+      case 48: hipLaunchKernelGGL((k_gather_lists<N, Op, 48>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
+      default: hipLaunchKernelGGL((k_gather_lists<N, Op, 32>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
+    }
+    LAUNCH_CHECK(ctx);
+    return PBF_OK;
+  }
+  constexpr int BZ = kBrickZ, THREADS = 256;
+  using B = Brick2<BZ>;
+  using Src = typename Op::Src;
+  // LDS per workgroup = header + tile[cap] + list[lmax][THREADS]; defaults give 2 workgroups per CU
+  // (tile sized for the 1.84x over-dense start lattice: 216 cells x 11.7) — see DESIGN.md
+  uint32_t cap = ctx->tileCap ? ctx->tileCap : (sizeof(Src) == 16 ? 3072u : 1536u);
+  uint32_t lmax = Op::kFilter ? (ctx->listMax ? std::max(ctx->listMax, 40u) : 56u) : 0u;
+  if (cap > 65535u) cap = 65535u;  // list entries are uint16 record indices
+  const size_t lds = B::HDR2 + size_t(cap) * sizeof(Src) + size_t(lmax) * THREADS * 2;
+  if (lds > 160 * 1024 - 64) return fail(ctx, PBF_ERR_INVALID, "tile cap / list max exceed the CU's 160 KiB LDS");
+  auto kernel = k_gather_bricks<N, Op, BZ, THREADS>;
+  static size_t attrSet = 0;  // per instantiation
+  if (lds > attrSet) {
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    int(lds)));
+    attrSet = lds;
+  }
+  const uint32_t perCU = uint32_t(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 64))));
+  if (ctx->gatherSeq >= kTickets) {  // more gather launches than tickets since the last sort: re-arm
+    HIPCHK(ctx, hipMemsetAsync(ctx->brickCtl.as<uint32_t>() + 1, 0, kTickets * 4, ctx->stream));
+    ctx->gatherSeq = 0;
+  }
+  uint32_t *ctl = ctx->brickCtl.as<uint32_t>();
+  hipLaunchKernelGGL(kernel, dim3(uint32_t(ctx->numCUs) * perCU), dim3(THREADS), lds, ctx->stream, c, args, key,
+                     table, ctx->bricks.as<const uint32_t>(), ctl, ctl + 1 + ctx->gatherSeq, cap, lmax);
+  ctx->gatherSeq++;
+  LAUNCH_CHECK(ctx);
+  return PBF_OK;
+}
+
 template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p) {
   StepConsts<N> c;
   if (int rc = make_consts<N>(ctx, p, c)) return rc;
   StageTimer t(ctx, ST_DIFFUSE);
   const int s = ctx->cur, d = 1 - s;  // col4[d] is free after the sort
-  hipLaunchKernelGGL((k_diffuse<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c,
-                     ctx->key[s].as<const uint32_t>(), ctx->table.as<const uint32_t>(),
-                     ctx->type[s].as<const uint8_t>(), ctx->col4[s].as<const vec4<N>>(), ctx->col4[d].as<vec4<N>>());
-  LAUNCH_CHECK(ctx);
+  typename DiffuseOp<N>::Args args{ctx->col4[s].as<const vec4<N>>(), ctx->col4[d].as<vec4<N>>(),
+                                   ctx->type[s].as<const uint8_t>()};
+  if (int rc = launch_gather<N, DiffuseOp<N>>(ctx, c, args)) return rc;
   std::swap(ctx->col4[s], ctx->col4[d]);
   return PBF_OK;
 }
@@ -344,16 +415,14 @@ template <typename N> int stage_lambda(pbf_ctx *ctx, const pbf_params *p) {
   if (int rc = make_consts<N>(ctx, p, c)) return rc;
   StageTimer t(ctx, ST_LAMBDA);
   const int s = ctx->cur;
-  auto launch = [&](auto fastTag) {
-    constexpr bool FAST = decltype(fastTag)::value;
-    hipLaunchKernelGGL((k_lambda<N, FAST>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c,
-                       ctx->key[s].as<const uint32_t>(), ctx->table.as<const uint32_t>(),
-                       ctx->type[s].as<const uint8_t>(), ctx->pos4[s].as<const vec4<N>>(),
-                       ctx->pstar[ctx->pcur].as<vec4<N>>());
-  };
-  if (ctx->fast) launch(std::true_type{}); else launch(std::false_type{});
-  LAUNCH_CHECK(ctx);
-  return PBF_OK;
+  if (ctx->fast) {
+    typename LambdaOp<N, true>::Args args{ctx->pstar[ctx->pcur].as<vec4<N>>(), ctx->pos4[s].as<const vec4<N>>(),
+                                          ctx->type[s].as<const uint8_t>()};
+    return launch_gather<N, LambdaOp<N, true>>(ctx, c, args);
+  }
+  typename LambdaOp<N, false>::Args args{ctx->pstar[ctx->pcur].as<vec4<N>>(), ctx->pos4[s].as<const vec4<N>>(),
+                                         ctx->type[s].as<const uint8_t>()};
+  return launch_gather<N, LambdaOp<N, false>>(ctx, c, args);
 }
 
 template <typename N> int stage_delta(pbf_ctx *ctx, const pbf_params *p) {
@@ -361,15 +430,17 @@ template <typename N> int stage_delta(pbf_ctx *ctx, const pbf_params *p) {
   if (int rc = make_consts<N>(ctx, p, c)) return rc;
   StageTimer t(ctx, ST_DELTA);
   const int s = ctx->cur, in = ctx->pcur, out = other_pstar(ctx);
-  auto launch = [&](auto fastTag) {
-    constexpr bool FAST = decltype(fastTag)::value;
-    hipLaunchKernelGGL((k_delta<N, FAST>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c,
-                       ctx->key[s].as<const uint32_t>(), ctx->table.as<const uint32_t>(),
-                       ctx->type[s].as<const uint8_t>(), ctx->pstar[in].as<const vec4<N>>(),
-                       ctx->pstar[out].as<vec4<N>>());
-  };
-  if (ctx->fast) launch(std::true_type{}); else launch(std::false_type{});
-  LAUNCH_CHECK(ctx);
+  int rc;
+  if (ctx->fast) {
+    typename DeltaOp<N, true>::Args args{ctx->pstar[in].as<const vec4<N>>(), ctx->pstar[out].as<vec4<N>>(),
+                                         ctx->type[s].as<const uint8_t>()};
+    rc = launch_gather<N, DeltaOp<N, true>>(ctx, c, args);
+  } else {
+    typename DeltaOp<N, false>::Args args{ctx->pstar[in].as<const vec4<N>>(), ctx->pstar[out].as<vec4<N>>(),
+                                          ctx->type[s].as<const uint8_t>()};
+    rc = launch_gather<N, DeltaOp<N, false>>(ctx, c, args);
+  }
+  if (rc) return rc;
   ctx->pcur = out;
   return PBF_OK;
 }
@@ -473,6 +544,17 @@ extern "C" {
 
 int pbf_abi_version(void) { return PBF_ABI_VERSION; }
 
+int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
+  if (!ctx || !name) return PBF_ERR_INVALID;
+  const std::string n(name);
+  if (n == "list_max") ctx->listMax = uint32_t(value);
+  else if (n == "gather") ctx->gatherKind = int(value);
+  else if (n == "tile_cap") ctx->tileCap = uint32_t(value);
+  else if (n == "probe") ctx->probe = uint32_t(value);
+  else return fail(ctx, PBF_ERR_INVALID, "unknown option " + n);
+  return PBF_OK;
+}
+
 int pbf_create(const pbf_desc *desc, pbf_ctx **out) {
   if (!desc || !out) {
     g_create_error = "pbf_create: NULL argument";
@@ -512,6 +594,11 @@ int pbf_create(const pbf_desc *desc, pbf_ctx **out) {
   ctx->device = desc->device;
   ctx->fp64 = desc->fp64 != 0;
   ctx->fast = (desc->flags & PBF_FLAG_FAST_MATH) != 0;
+  ctx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char *e = std::getenv("PBF_TILE_CAP")) ctx->tileCap = uint32_t(std::atoi(e));
+  if (const char *e = std::getenv("PBF_PROBE")) ctx->probe = uint32_t(std::atoi(e));
+  if (const char *e = std::getenv("PBF_GATHER")) ctx->gatherKind = std::atoi(e);
+  if (const char *e = std::getenv("PBF_LIST_MAX")) ctx->listMax = uint32_t(std::atoi(e));
   if ((e = hipSetDevice(ctx->device)) != hipSuccess) {
     g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
     delete ctx;
@@ -543,7 +630,7 @@ void pbf_destroy(pbf_ctx *ctx) {
   DevBuf *all[] = {&ctx->pos4[0], &ctx->pos4[1], &ctx->vel4[0], &ctx->vel4[1], &ctx->col4[0],  &ctx->col4[1],
                    &ctx->id[0],   &ctx->id[1],   &ctx->type[0], &ctx->type[1], &ctx->key[0],   &ctx->key[1],
                    &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2], &ctx->count, &ctx->table,   &ctx->blockSums,
-                   &ctx->permTmp, &ctx->wells,   &ctx->staging};
+                   &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl};
   for (DevBuf *b : all)
     if (b->p) (void)hipFree(b->p);
   if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);

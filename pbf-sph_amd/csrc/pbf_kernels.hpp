@@ -84,8 +84,8 @@ __device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
 }
 
 // block-wide exclusive scan of one value per thread; returns the exclusive prefix, total in *total
-__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *total) {
-  __shared__ uint32_t waveSum[BLOCK / 64];
+template <int THREADS = BLOCK> __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *total) {
+  __shared__ uint32_t waveSum[THREADS / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t incl = wave_incl_scan(v, lane);
   __syncthreads();  // protect waveSum across back-to-back calls
@@ -93,7 +93,7 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *total) {
   __syncthreads();
   uint32_t off = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < BLOCK / 64; ++w) {
+  for (int w = 0; w < THREADS / 64; ++w) {
     const uint32_t s = waveSum[w];
     if (w < wave) off += s;
     tot += s;
@@ -255,20 +255,24 @@ template <typename N, bool FAST> struct PairGeom {
   N hr2_over_r;  // (h - r)^2 / r, valid when inSpiky
   bool inH, inSpiky;
 };
+__device__ inline float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ inline double fast_rsq(double x) { return 1.0 / sqrt(x); }  // fp64 keeps the IEEE forms
+
 template <typename N, bool FAST>
 __device__ inline PairGeom<N, FAST> pair_geom(const vec4<N> &a, const vec4<N> &b, N h) {
   PairGeom<N, FAST> g;
   const N bx = b.x - a.x, by = b.y - a.y, bz = b.z - a.z;  // distance(a,b) = length(b - a)
-  const N d2 = bx * bx + by * by + bz * bz;
   g.dx = a.x - b.x, g.dy = a.y - b.y, g.dz = a.z - b.z;
   if constexpr (FAST) {
-    const N rinv = rsqrt(d2);
-    g.r = d2 > N(0) ? d2 * rinv : N(0);
-    g.inH = g.r <= h;
-    g.inSpiky = g.inH && g.r >= N(EPSILON);
+    const N d2 = fma(bz, bz, fma(by, by, bx * bx));
+    const N rinv = fast_rsq(d2);
+    g.inSpiky = d2 <= h * h && d2 >= N(EPSILON) * N(EPSILON);
+    g.inH = d2 <= h * h;
+    g.r = g.inSpiky ? d2 * rinv : N(0);
     const N hr = h - g.r;
     g.hr2_over_r = (hr * hr) * rinv;
   } else {
+    const N d2 = bx * bx + by * by + bz * bz;
     g.r = sqrt(d2);
     g.inH = g.r <= h;
     g.inSpiky = g.inH && g.r >= N(EPSILON);
@@ -278,62 +282,91 @@ __device__ inline PairGeom<N, FAST> pair_geom(const vec4<N> &a, const vec4<N> &b
   return g;
 }
 
-// ------------------------------------------------------------------------------------------------
-// diffuse (ompsph.hpp:188-207), Jacobi like the OpenCL kernel (ocl/oclsph_kernel.h:67-93)
-// ------------------------------------------------------------------------------------------------
-template <typename N>
-__global__ __launch_bounds__(BLOCK) void k_diffuse(StepConsts<N> c, const uint32_t *__restrict__ key,
-                                                   const uint32_t *__restrict__ table,
-                                                   const uint8_t *__restrict__ type,
-                                                   const vec4<N> *__restrict__ colIn, vec4<N> *__restrict__ colOut) {
-  const uint32_t a = blockIdx.x * BLOCK + threadIdx.x;
-  if (a >= c.n) return;
-  const vec4<N> ca = colIn[a];
-  if (c.hasObstacles && type[a] == 1) {
-    colOut[a] = ca;
-    return;
-  }
-  N mx = 0, my = 0, mz = 0, mw = 0;
-  int nn = 0;
-  for_each_candidate(key[a], table, c.tableN, [&](uint32_t b) {
-    if (c.hasObstacles && type[b] == 1) return;
-    const vec4<N> cb = colIn[b];
-    mx += cb.x, my += cb.y, mz += cb.z, mw += cb.w;
-    ++nn;
-  });
-  vec4<N> out = ca;
-  if (nn != 0) {
-    const N fn = N(nn), t = c.diffuseT;
-    auto one = [&](N x, N m) {
-      const N y = (m / fn) * N(1.33);
-      const N o = x * (N(1) - t) + y * t;
-      return min(max(o, N(0.03)), N(1.0));
-    };
-    out = make_vec4<N>(one(ca.x, mx), one(ca.y, my), one(ca.z, mz), one(ca.w, mw));
-  }
-  colOut[a] = out;
+// Conservative "may be within h" test used to FILTER candidates before the exact pair terms:
+// d2 (any rounding order) <= h^2 (1 + 1e-5) holds for every pair the exact test r <= h admits, and a
+// candidate it rejects contributes exactly +0 to every sum — so filtering never changes a bit.
+template <typename N> __device__ inline bool maybe_within_h(const vec4<N> &a, const vec4<N> &b, N h2filter) {
+  const N bx = b.x - a.x, by = b.y - a.y, bz = b.z - a.z;
+  return fma(bz, bz, fma(by, by, bx * bx)) <= h2filter;
 }
 
 // ------------------------------------------------------------------------------------------------
+// The three 27-cell gather stages as "ops": begin(i) loads particle a (false = nothing to do),
+// add(b) folds one candidate in the reference's visiting order, end(i) stores the result.
+// Both gather kernels below (global-memory walk and LDS-tiled walk) run the SAME op code in the
+// SAME candidate order, so their results are bit-identical to each other and to the oracle.
+// ------------------------------------------------------------------------------------------------
+
+// diffuse (ompsph.hpp:188-207), Jacobi like the OpenCL kernel (ocl/oclsph_kernel.h:67-93)
+template <typename N> struct DiffuseOp {
+  using Src = vec4<N>;
+  struct Args {
+    const vec4<N> *colIn;
+    vec4<N> *colOut;
+    const uint8_t *type;
+  };
+  static constexpr bool kNeedsCandidateType = true;  // obstacles are skipped as candidates (ompsph.hpp:194)
+  static constexpr bool kFilter = false;             // no distance test in diffuse: every candidate counts
+  __device__ bool near(const StepConsts<N> &, const Src &) const { return true; }
+  __device__ static const Src *src(const Args &a) { return a.colIn; }
+  vec4<N> ca;
+  N mx, my, mz, mw;
+  int nn;
+  __device__ bool begin(const StepConsts<N> &c, const Args &a, uint32_t i) {
+    ca = a.colIn[i];
+    mx = my = mz = mw = N(0);
+    nn = 0;
+    if (c.hasObstacles && a.type[i] == 1) {
+      a.colOut[i] = ca;
+      return false;
+    }
+    return true;
+  }
+  __device__ void add(const StepConsts<N> &, const Src &cb) {
+    mx += cb.x, my += cb.y, mz += cb.z, mw += cb.w;
+    ++nn;
+  }
+  __device__ void end(const StepConsts<N> &c, const Args &a, uint32_t i) {
+    vec4<N> out = ca;
+    if (nn != 0) {
+      const N fn = N(nn), t = c.diffuseT;
+      auto one = [&](N x, N m) {
+        const N y = (m / fn) * N(1.33);
+        const N o = x * (N(1) - t) + y * t;
+        return min(max(o, N(0.03)), N(1.0));
+      };
+      out = make_vec4<N>(one(ca.x, mx), one(ca.y, my), one(ca.z, mz), one(ca.w, mw));
+    }
+    a.colOut[i] = out;
+  }
+};
+
 // lambda (ompsph.hpp:217-232): rho = sum m_a poly6; g = sum grad spiky / rho0;
 // lambda = -(rho/rho0 - 1) / (|g|^2 + 600).  Written into pstar[a].w (only xyz is read here).
-// ------------------------------------------------------------------------------------------------
-template <typename N, bool FAST>
-__global__ __launch_bounds__(BLOCK) void k_lambda(StepConsts<N> c, const uint32_t *__restrict__ key,
-                                                  const uint32_t *__restrict__ table,
-                                                  const uint8_t *__restrict__ type, const vec4<N> *__restrict__ pos4,
-                                                  vec4<N> *__restrict__ pstar) {
-  const uint32_t a = blockIdx.x * BLOCK + threadIdx.x;
-  if (a >= c.n) return;
-  if (c.hasObstacles && type[a] == 1) {
-    pstar[a].w = N(0);
-    return;
+template <typename N, bool FAST> struct LambdaOp {
+  using Src = vec4<N>;
+  struct Args {
+    vec4<N> *pstar;
+    const vec4<N> *pos4;
+    const uint8_t *type;
+  };
+  static constexpr bool kNeedsCandidateType = false;
+  static constexpr bool kFilter = true;
+  __device__ bool near(const StepConsts<N> &c, const Src &pb) const { return maybe_within_h<N>(pa, pb, c.h2filter); }
+  __device__ static const Src *src(const Args &a) { return a.pstar; }
+  vec4<N> pa;
+  N mass, gx, gy, gz, rho;
+  __device__ bool begin(const StepConsts<N> &c, const Args &a, uint32_t i) {
+    if (c.hasObstacles && a.type[i] == 1) {
+      a.pstar[i].w = N(0);
+      return false;
+    }
+    pa = a.pstar[i];
+    mass = a.pos4[i].w;
+    gx = gy = gz = rho = N(0);
+    return true;
   }
-  const vec4<N> pa = pstar[a];
-  const N mass = pos4[a].w;
-  N gx = 0, gy = 0, gz = 0, rho = 0;
-  for_each_candidate(key[a], table, c.tableN, [&](uint32_t b) {
-    const vec4<N> pb = pstar[b];
+  __device__ void add(const StepConsts<N> &c, const Src &pb) {
     const auto g = pair_geom<N, FAST>(pa, pb, c.h);
     if (g.inSpiky) {
       const N s = c.spikyFactor * g.hr2_over_r;
@@ -343,47 +376,403 @@ __global__ __launch_bounds__(BLOCK) void k_lambda(StepConsts<N> c, const uint32_
       const N d = (c.h * c.h) - g.r * g.r;
       rho += mass * (c.poly6Factor * (d * d * d));
     }
-  });
-  const N norm2 = gx * gx + gy * gy + gz * gz;
-  const N Ci = rho / N(RHO) - N(1);
-  pstar[a].w = -Ci / (norm2 + N(CFM_EPSILON));
-}
-
-// ------------------------------------------------------------------------------------------------
-// delta-p + clamp (ompsph.hpp:235-248), Jacobi: reads pstarIn (xyz + lambda), writes pstarOut.
-// ------------------------------------------------------------------------------------------------
-template <typename N, bool FAST>
-__global__ __launch_bounds__(BLOCK) void k_delta(StepConsts<N> c, const uint32_t *__restrict__ key,
-                                                 const uint32_t *__restrict__ table,
-                                                 const uint8_t *__restrict__ type,
-                                                 const vec4<N> *__restrict__ pstarIn,
-                                                 vec4<N> *__restrict__ pstarOut) {
-  const uint32_t a = blockIdx.x * BLOCK + threadIdx.x;
-  if (a >= c.n) return;
-  const vec4<N> pa = pstarIn[a];
-  if (c.hasObstacles && type[a] == 1) {
-    pstarOut[a] = pa;
-    return;
   }
-  N ax = 0, ay = 0, az = 0;
-  for_each_candidate(key[a], table, c.tableN, [&](uint32_t b) {
-    const vec4<N> pb = pstarIn[b];
+  __device__ void end(const StepConsts<N> &, const Args &a, uint32_t i) {
+    const N norm2 = gx * gx + gy * gy + gz * gz;
+    const N Ci = rho / N(RHO) - N(1);
+    a.pstar[i].w = -Ci / (norm2 + N(CFM_EPSILON));
+  }
+};
+
+// delta-p + clamp (ompsph.hpp:235-248), Jacobi: reads pstarIn (xyz + lambda), writes pstarOut.
+template <typename N, bool FAST> struct DeltaOp {
+  using Src = vec4<N>;
+  struct Args {
+    const vec4<N> *pstarIn;
+    vec4<N> *pstarOut;
+    const uint8_t *type;
+  };
+  static constexpr bool kNeedsCandidateType = false;
+  static constexpr bool kFilter = true;
+  __device__ bool near(const StepConsts<N> &c, const Src &pb) const { return maybe_within_h<N>(pa, pb, c.h2filter); }
+  __device__ static const Src *src(const Args &a) { return a.pstarIn; }
+  vec4<N> pa;
+  N ax, ay, az;
+  __device__ bool begin(const StepConsts<N> &c, const Args &a, uint32_t i) {
+    pa = a.pstarIn[i];
+    ax = ay = az = N(0);
+    if (c.hasObstacles && a.type[i] == 1) {
+      a.pstarOut[i] = pa;
+      return false;
+    }
+    return true;
+  }
+  __device__ void add(const StepConsts<N> &c, const Src &pb) {
     const auto g = pair_geom<N, FAST>(pa, pb, c.h);
     if (g.inSpiky) {  // outside it the gradient is zero, so corr / factor are irrelevant
       const N d = (c.h * c.h) - g.r * g.r;
       const N q = (c.poly6Factor * (d * d * d)) / c.p6DeltaQ;
       const N q2 = q * q;
-      const N corr = N(-CorrK) * (q2 * q2);
+      const N corr = N(-CorrK) * (q2 * q2);  // pow(q, CorrN = 4) of ompsph.hpp:240
       const N factor = (pa.w + pb.w + corr) / N(RHO);
       const N s = c.spikyFactor * g.hr2_over_r;
       ax += (g.dx * s) * factor, ay += (g.dy * s) * factor, az += (g.dz * s) * factor;
     }
-  });
-  N x = (pa.x + ax) * c.scale, y = (pa.y + ay) * c.scale, z = (pa.z + az) * c.scale;
-  x = min(c.maxB[0], max(c.minB[0], x));
-  y = min(c.maxB[1], max(c.minB[1], y));
-  z = min(c.maxB[2], max(c.minB[2], z));
-  pstarOut[a] = make_vec4<N>(x / c.scale, y / c.scale, z / c.scale, pa.w);
+  }
+  __device__ void end(const StepConsts<N> &c, const Args &a, uint32_t i) {
+    N x = (pa.x + ax) * c.scale, y = (pa.y + ay) * c.scale, z = (pa.z + az) * c.scale;
+    x = min(c.maxB[0], max(c.minB[0], x));
+    y = min(c.maxB[1], max(c.minB[1], y));
+    z = min(c.maxB[2], max(c.minB[2], z));
+    a.pstarOut[i] = make_vec4<N>(x / c.scale, y / c.scale, z / c.scale, pa.w);
+  }
+};
+
+// One particle through the global-memory 27-cell walk.
+template <typename N, typename Op>
+__device__ inline void gather_one_global(const StepConsts<N> &c, const typename Op::Args &args,
+                                         const uint32_t *__restrict__ key, const uint32_t *__restrict__ table,
+                                         uint32_t i) {
+  Op op;
+  if (!op.begin(c, args, i)) return;
+  const typename Op::Src *src = Op::src(args);
+  if (c.probe == 0) {
+    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) {
+      if (Op::kNeedsCandidateType && c.hasObstacles && args.type[b] == 1) return;
+      op.add(c, src[b]);
+    });
+  } else if (c.probe == 1) {  // diagnostic: memory side only
+    N acc = 0;
+    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { acc += src[b].x; });
+    if (acc == N(12345.678)) op.add(c, src[i]);
+  } else {  // diagnostic: pair math only (candidate synthesised from the loop index, no candidate loads)
+    const typename Op::Src me = src[i];
+    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) {
+      typename Op::Src f = me;
+      f.x += N(b & 63u) * N(0.002), f.y += N((b >> 6) & 63u) * N(0.001);
+      op.add(c, f);
+    });
+  }
+  op.end(c, args, i);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gather kernel A — one thread per particle, candidates straight from global memory (L1/L2).
+// The simple form: used for A/B comparison (PBF_FLAG_NO_LDS), for diffuse when obstacles exist, and
+// as the in-kernel fallback of kernel B.
+// ------------------------------------------------------------------------------------------------
+template <typename N, typename Op>
+__global__ __launch_bounds__(BLOCK) void k_gather_global(StepConsts<N> c, typename Op::Args args,
+                                                         const uint32_t *__restrict__ key,
+                                                         const uint32_t *__restrict__ table) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= c.n) return;
+  gather_one_global<N, Op>(c, args, key, table, i);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gather kernel B — LDS-tiled.  One workgroup owns a Morton-aligned brick of 4 x 4 x BZ cells:
+// 16*BZ consecutive Morton codes, i.e. ONE contiguous run of sorted particles.  It stages the
+// brick's 6 x 6 x (BZ+2) halo of cells into LDS once — cell start/end from the grid table, then the
+// candidates' 16-byte (fp32) records — laid out x-fastest, so that for any home cell the three
+// x-adjacent neighbour cells are one contiguous LDS run: a particle walks 9 runs instead of 27 cell
+// ranges, in exactly the reference's order (sph.hpp:220-234).  Each candidate record is fetched
+// from L2/HBM ~3.4x (BZ=4) per launch instead of ~100x through L1.
+//   LDS: [0, 4*(HALO+1)) run offsets | [.., +4*HALO) global starts | 16-byte aligned tile[cap]
+// A brick whose halo holds more than `cap` records (piles at walls) falls back to the global walk.
+// Blocks >= nBricks sweep the particles that lie in no cell (key >= tableN, sph.hpp:206).
+// ------------------------------------------------------------------------------------------------
+template <int BZ> struct Brick {
+  static constexpr int HOME = 16 * BZ;            // Morton codes per brick
+  static constexpr int HZ = BZ + 2;               // halo depth in z
+  static constexpr int HALO = 36 * HZ;            // 6 x 6 x (BZ+2) cells
+  static constexpr int HDR = ((2 * HALO + 1) * 4 + 15) / 16 * 16;  // header bytes, keeps the tile 16-B aligned
+};
+
+template <typename N, typename Op, int BZ>
+__global__ __launch_bounds__(BLOCK) void k_gather_tiled(StepConsts<N> c, typename Op::Args args,
+                                                        const uint32_t *__restrict__ key,
+                                                        const uint32_t *__restrict__ table, uint32_t nBricks,
+                                                        uint32_t cap) {
+  using B = Brick<BZ>;
+  using Src = typename Op::Src;
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t *off = reinterpret_cast<uint32_t *>(smem);  // [HALO + 1]
+  uint32_t *gstart = off + B::HALO + 1;                // [HALO]
+  Src *tile = reinterpret_cast<Src *>(smem + B::HDR);
+  const uint32_t tid = threadIdx.x;
+
+  if (blockIdx.x >= nBricks) {  // particles in no cell: they still gather from their 27 neighbour codes
+    const uint32_t stride = (gridDim.x - nBricks) * BLOCK;
+    for (uint32_t i = table[c.tableN] + (blockIdx.x - nBricks) * BLOCK + tid; i < c.n; i += stride)
+      gather_one_global<N, Op>(c, args, key, table, i);
+    return;
+  }
+
+  const uint32_t code0 = blockIdx.x * B::HOME;
+  const uint32_t hs = table[code0];
+  const uint32_t he = table[min(code0 + uint32_t(B::HOME), c.tableN)];
+  if (hs == he) return;  // empty brick (uniform across the workgroup)
+
+  // ---- phase 1: the halo's cell ranges and their exclusive scan --------------------------------
+  const uint32_t bx = compact10(code0), by = compact10(code0 >> 1), bz = compact10(code0 >> 2);
+  uint32_t cnt = 0;
+  if (tid < B::HALO) {
+    const uint32_t lx = tid % 6, ly = (tid / 6) % 6, lz = tid / 36;
+    // +-1 wraps modulo 1024 exactly like curves.h's encode keeps the low 10 bits
+    const uint32_t code = morton_encode((bx + lx - 1u) & 1023u, (by + ly - 1u) & 1023u, (bz + lz - 1u) & 1023u);
+    uint32_t s = 0, e = 0;
+    if (code < c.tableN) {  // sph.hpp:206-208
+      s = table[code];
+      e = (code + 1u) < c.tableN ? table[code + 1u] : s;
+    }
+    gstart[tid] = s;
+    cnt = e - s;
+  }
+  uint32_t total;
+  const uint32_t ex = block_excl_scan(cnt, &total);
+  if (tid < B::HALO) off[tid] = ex;
+  if (tid == 0) off[B::HALO] = total;
+  __syncthreads();
+
+  const Src *src = Op::src(args);
+  const bool tiled = total <= cap && !(Op::kNeedsCandidateType && c.hasObstacles);
+  if (tiled) {
+    // ---- phase 2: stage the candidates (one halo cell per thread; a cell is one or two cache lines)
+    if (tid < B::HALO) {
+      const uint32_t s = gstart[tid], o = off[tid];
+      for (uint32_t j = 0; j < cnt; ++j) tile[o + j] = src[s + j];
+    }
+    __syncthreads();
+    // ---- phase 3: every home particle walks its 9 x-runs out of LDS -----------------------------
+    for (uint32_t i = hs + tid; i < he; i += BLOCK) {
+      Op op;
+      if (!op.begin(c, args, i)) continue;
+      const uint32_t k = key[i];
+      const uint32_t hx = (k & 1u) | ((k >> 2) & 2u);         // bits 0, 3
+      const uint32_t hy = ((k >> 1) & 1u) | ((k >> 3) & 2u);  // bits 1, 4
+      const uint32_t hz = BZ == 4 ? (((k >> 2) & 1u) | ((k >> 4) & 2u)) : ((k >> 2) & 1u);  // bits 2, (5)
+#pragma unroll 1
+      for (uint32_t dz = 0; dz < 3; ++dz)
+#pragma unroll 1
+        for (uint32_t dy = 0; dy < 3; ++dy) {
+          const uint32_t l0 = ((hz + dz) * 6u + (hy + dy)) * 6u + hx;
+          const uint32_t s = off[l0], e = off[l0 + 3];
+          for (uint32_t j = s; j < e; ++j) op.add(c, tile[j]);
+        }
+      op.end(c, args, i);
+    }
+  } else {
+    for (uint32_t i = hs + tid; i < he; i += BLOCK) gather_one_global<N, Op>(c, args, key, table, i);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gather kernel C — kernel B made persistent and filtered.
+//   * persistent workgroups pull bricks from a device-side list of NON-EMPTY bricks through an
+//     atomic ticket (k_brick_list builds the list during the sort stage), so the ~90 % of bricks
+//     that hold no fluid never cost a launch slot; the loop ends when the ticket passes the list
+//     end — every wave reaches that exit;
+//   * for lambda / delta each lane first FILTERS its ~100 candidates with the conservative
+//     maybe_within_h test (3 sub + 3 fma + cmp out of LDS) into a per-lane list of LDS record
+//     indices (uint16, laid out [slot][thread] so a wave's accesses are consecutive), then runs
+//     the exact pair terms only over the ~25 that survive, still in the reference's visiting order.
+//     Rejected candidates contribute exactly +0, so every result bit is unchanged.
+//   LDS: header (run offsets, global starts, ticket) | tile[cap] records | list[lmax][THREADS] u16
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_brick_list(const uint32_t *__restrict__ table, uint32_t tableN,
+                                                      uint32_t home, uint32_t nBricks,
+                                                      uint32_t *__restrict__ active,
+                                                      uint32_t *__restrict__ nActive) {
+  const uint32_t b = blockIdx.x * BLOCK + threadIdx.x;
+  if (b >= nBricks) return;
+  const uint32_t s = table[b * home], e = table[min((b + 1u) * home, tableN)];
+  if (e > s) active[atomicAdd(nActive, 1u)] = b;  // order is arbitrary: it only schedules, never reorders sums
+}
+
+template <int BZ> struct Brick2 : Brick<BZ> {
+  static constexpr int HDR2 = ((2 * Brick<BZ>::HALO + 1 + 1) * 4 + 15) / 16 * 16;  // + the ticket word
+};
+
+template <typename N, typename Op, int BZ, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_gather_bricks(StepConsts<N> c, typename Op::Args args,
+                                                           const uint32_t *__restrict__ key,
+                                                           const uint32_t *__restrict__ table,
+                                                           const uint32_t *__restrict__ active,
+                                                           const uint32_t *__restrict__ nActivePtr,
+                                                           uint32_t *__restrict__ ticket, uint32_t cap,
+                                                           uint32_t lmax) {
+  using B = Brick2<BZ>;
+  using Src = typename Op::Src;
+  static_assert(B::HALO <= THREADS, "one halo cell per thread in phase 1/2");
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t *off = reinterpret_cast<uint32_t *>(smem);  // [HALO + 1]
+  uint32_t *gstart = off + B::HALO + 1;                // [HALO]
+  uint32_t *shTicket = gstart + B::HALO;               // [1]
+  Src *tile = reinterpret_cast<Src *>(smem + B::HDR2);
+  uint16_t *list = reinterpret_cast<uint16_t *>(smem + B::HDR2 + size_t(cap) * sizeof(Src));
+  const uint32_t tid = threadIdx.x;
+  const uint32_t nActive = *nActivePtr;
+  const Src *src = Op::src(args);
+  // the last workgroups also sweep the particles that lie in no cell (key >= tableN, sph.hpp:206)
+  {
+    const uint32_t stride = gridDim.x * THREADS;
+    for (uint32_t i = table[c.tableN] + blockIdx.x * THREADS + tid; i < c.n; i += stride)
+      gather_one_global<N, Op>(c, args, key, table, i);
+  }
+
+  for (;;) {
+    __syncthreads();  // previous brick's LDS reads are done before the header / tile are rewritten
+    if (tid == 0) *shTicket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t t = *shTicket;
+    if (t >= nActive) break;  // uniform: every wave of the workgroup leaves here
+    const uint32_t brick = active[t];
+    const uint32_t code0 = brick * B::HOME;
+    const uint32_t hs = table[code0];
+    const uint32_t he = table[min(code0 + uint32_t(B::HOME), c.tableN)];
+
+    // ---- phase 1: the halo's cell ranges and their exclusive scan ------------------------------
+    const uint32_t bx = compact10(code0), by = compact10(code0 >> 1), bz = compact10(code0 >> 2);
+    uint32_t cnt = 0;
+    if (tid < B::HALO) {
+      const uint32_t lx = tid % 6, ly = (tid / 6) % 6, lz = tid / 36;
+      const uint32_t code = morton_encode((bx + lx - 1u) & 1023u, (by + ly - 1u) & 1023u, (bz + lz - 1u) & 1023u);
+      uint32_t s = 0, e = 0;
+      if (code < c.tableN) {  // sph.hpp:206-208
+        s = table[code];
+        e = (code + 1u) < c.tableN ? table[code + 1u] : s;
+      }
+      gstart[tid] = s;
+      cnt = e - s;
+    }
+    uint32_t total;
+    const uint32_t ex = block_excl_scan<THREADS>(cnt, &total);
+    if (tid < B::HALO) off[tid] = ex;
+    if (tid == 0) off[B::HALO] = total;
+    __syncthreads();
+
+    const bool tiled = total <= cap && !(Op::kNeedsCandidateType && c.hasObstacles);
+    if (!tiled) {  // pile-up beyond the tile, or diffuse with obstacles: plain global walk
+      for (uint32_t i = hs + tid; i < he; i += THREADS) gather_one_global<N, Op>(c, args, key, table, i);
+      continue;
+    }
+    // ---- phase 2: stage the candidates ------------------------------------------------------------
+    if (tid < B::HALO) {
+      const uint32_t s = gstart[tid], o = off[tid];
+      for (uint32_t j = 0; j < cnt; ++j) tile[o + j] = src[s + j];
+    }
+    __syncthreads();
+    // ---- phase 3: every home particle walks its 9 x-runs out of LDS -------------------------------
+    for (uint32_t i = hs + tid; i < he; i += THREADS) {
+      Op op;
+      if (!op.begin(c, args, i)) continue;
+      const uint32_t k = key[i];
+      const uint32_t hx = (k & 1u) | ((k >> 2) & 2u);         // bits 0, 3
+      const uint32_t hy = ((k >> 1) & 1u) | ((k >> 3) & 2u);  // bits 1, 4
+      const uint32_t hz = BZ == 4 ? (((k >> 2) & 1u) | ((k >> 4) & 2u)) : ((k >> 2) & 1u);  // bits 2, (5)
+      if constexpr (Op::kFilter) {
+        uint32_t nl = 0;
+        auto flush = [&]() {
+          for (uint32_t q = 0; q < nl; ++q) op.add(c, tile[list[q * THREADS + tid]]);
+          nl = 0;
+        };
+#pragma unroll 1
+        for (uint32_t dz = 0; dz < 3; ++dz)
+#pragma unroll 1
+          for (uint32_t dy = 0; dy < 3; ++dy) {
+            const uint32_t l0 = ((hz + dz) * 6u + (hy + dy)) * 6u + hx;
+            const uint32_t s = off[l0], e = off[l0 + 3];
+#pragma unroll 4
+            for (uint32_t j = s; j < e; ++j) {
+              const bool hit = op.near(c, tile[j]);
+              list[nl * THREADS + tid] = uint16_t(j);  // branch-free append: the slot is kept only on a hit
+              nl += hit ? 1u : 0u;
+              if (nl == lmax) flush();  // rare: a lane with more than lmax neighbours drains in order
+            }
+          }
+        flush();
+      } else {
+#pragma unroll 1
+        for (uint32_t dz = 0; dz < 3; ++dz)
+#pragma unroll 1
+          for (uint32_t dy = 0; dy < 3; ++dy) {
+            const uint32_t l0 = ((hz + dz) * 6u + (hy + dy)) * 6u + hx;
+            const uint32_t s = off[l0], e = off[l0 + 3];
+#pragma unroll 4
+            for (uint32_t j = s; j < e; ++j) op.add(c, tile[j]);
+          }
+      }
+      op.end(c, args, i);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gather kernel D — one lane per particle, candidates from global memory (L1/L2), two phases:
+//   A  every lane walks its 27 cell ranges as ONE flattened loop (wave-uniform trip count = the
+//      longest lane, not the sum of per-cell maxima) and applies the conservative maybe_within_h
+//      filter; survivors' global indices go to a per-lane list in LDS ([slot][thread], 4-byte);
+//   B  whenever any lane's list is full — and once at the end — ALL lanes drain their lists through
+//      the exact pair terms, in visiting order.  Rejected candidates contribute exactly +0, so
+//      results are bit-identical to the plain walk.
+// No tiles, no bricks: occupancy is set by the list alone (LMAX x 1 KiB per 256 threads), and sparse
+// splash regions cost the same per particle as the dense column.
+// ------------------------------------------------------------------------------------------------
+__device__ inline uint32_t neighbour_code(uint32_t xm, uint32_t ym, uint32_t zm, uint32_t ci) {
+  // ci = dx + 3 dy + 9 dz in the reference's order (sph.hpp:220-234); dilated +-1 per axis
+  const uint32_t dx = ci % 3u, dy = (ci / 3u) % 3u, dz = ci / 9u;
+  const uint32_t x = dx == 0 ? (xm - 1u) & MORTON_X : dx == 1 ? xm : ((xm | ~MORTON_X) + 1u) & MORTON_X;
+  const uint32_t y = dy == 0 ? (ym - 2u) & MORTON_Y : dy == 1 ? ym : ((ym | ~MORTON_Y) + 2u) & MORTON_Y;
+  const uint32_t z = dz == 0 ? (zm - 4u) & MORTON_Z : dz == 1 ? zm : ((zm | ~MORTON_Z) + 4u) & MORTON_Z;
+  return x | y | z;
+}
+
+template <typename N, typename Op, int LMAX>
+__global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typename Op::Args args,
+                                                        const uint32_t *__restrict__ key,
+                                                        const uint32_t *__restrict__ table) {
+  __shared__ uint32_t list[(Op::kFilter ? LMAX : 1) * BLOCK];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t i = blockIdx.x * BLOCK + tid;
+  Op op;
+  const bool live = i < c.n && op.begin(c, args, i);
+  const typename Op::Src *src = Op::src(args);
+  const uint32_t k = live ? key[i] : 0u;
+  const uint32_t xm = k & MORTON_X, ym = k & MORTON_Y, zm = k & MORTON_Z;
+  uint32_t ci = live ? 0u : 27u, j = 0, e = 0, nl = 0;
+  auto drain = [&]() {
+#pragma unroll 2
+    for (uint32_t q = 0; q < nl; ++q) op.add(c, src[list[q * BLOCK + tid]]);
+    nl = 0;
+  };
+  for (;;) {
+    while (j == e && ci < 27u) {  // next non-empty cell range (sph.hpp:205-208)
+      const uint32_t code = neighbour_code(xm, ym, zm, ci);
+      ++ci;
+      if (code < c.tableN) {
+        j = table[code];
+        e = (code + 1u) < c.tableN ? table[code + 1u] : j;
+      }
+    }
+    const bool has = j < e;
+    if (!__any(has)) break;  // wave-uniform: every lane has exhausted its 27 cells
+    if (has) {
+      if constexpr (Op::kFilter) {
+        const bool hit = op.near(c, src[j]);
+        list[nl * BLOCK + tid] = j;  // branch-free append: the slot is kept only on a hit
+        nl += hit ? 1u : 0u;
+      } else {
+        if (!(Op::kNeedsCandidateType && c.hasObstacles && args.type[j] == 1)) op.add(c, src[j]);
+      }
+      ++j;
+    }
+    if constexpr (Op::kFilter) {
+      if (__any(nl == uint32_t(LMAX))) drain();  // all lanes drain together, each in its own order
+    }
+  }
+  if constexpr (Op::kFilter) drain();
+  if (live) op.end(c, args, i);
 }
 
 // ------------------------------------------------------------------------------------------------

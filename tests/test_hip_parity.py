@@ -35,8 +35,9 @@ def by_id(d):
     return {k: v[o] for k, v in d.items()}
 
 
-def mk(pkg, oracle, scene, fp64, flags=0, device_pow=True):
+def mk(pkg, oracle, scene, fp64, flags=0, device_pow=True, gather=0):
     s = pkg.Solver(h=0.1, fp64=fp64, flags=flags)
+    s.set_option("gather", gather)
     s.upload(**scene)
     o = oracle.Oracle(fp64, device_pow=device_pow)
     o.set_particles(**scene)
@@ -69,14 +70,21 @@ def assert_state_equal(g, w, what=""):
 
 SCENES = ["cubes8192", "dam8192"]
 
+
+@pytest.fixture(params=["global", "lists", "bricks"])
+def variant(request):
+    """The three gather kernels must all be bit-identical to the oracle: 0 = per-particle global
+    walk (default), 1 = filtered per-lane lists, 2 = persistent LDS bricks."""
+    return {"global": 0, "lists": 1, "bricks": 2}[request.param]
+
 # ------------------------------------------------------------------------------------------ A
 
 
 @pytest.mark.parametrize("fp64", [False, True])
 @pytest.mark.parametrize("scene", SCENES)
-def test_every_stage_bit_exact(pkg, oracle, scene, fp64):
+def test_every_stage_bit_exact(pkg, oracle, scene, fp64, variant):
     sc, side = get_scene(pkg, scene, fp64)
-    s, o = mk(pkg, oracle, sc, fp64)
+    s, o = mk(pkg, oracle, sc, fp64, gather=variant)
     p, q = params_pair(pkg, oracle, side=side)
     for _ in range(2):  # leave the lattice first
         s.step(p)
@@ -113,10 +121,10 @@ def test_every_stage_bit_exact(pkg, oracle, scene, fp64):
 
 @pytest.mark.parametrize("fp64", [False, True])
 @pytest.mark.parametrize("scene", SCENES)
-def test_free_running_bit_exact(pkg, oracle, scene, fp64):
+def test_free_running_bit_exact(pkg, oracle, scene, fp64, variant):
     """12 frames without re-seeding: GPU state == oracle(device_pow) state, bit for bit."""
     sc, side = get_scene(pkg, scene, fp64)
-    s, o = mk(pkg, oracle, sc, fp64)
+    s, o = mk(pkg, oracle, sc, fp64, gather=variant)
     p, q = params_pair(pkg, oracle, side=side)
     for frame in range(12):
         s.step(p)
@@ -125,11 +133,11 @@ def test_free_running_bit_exact(pkg, oracle, scene, fp64):
             assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
 
 
-def test_moving_box_bit_exact(pkg, oracle):
+def test_moving_box_bit_exact(pkg, oracle, variant):
     """benchmark.cpp:33,47: every frame runs with applyMotionSinXCosZ(param, frame); the grid (and
     its table length) moves with the box."""
     sc, side = get_scene(pkg, "cubes8192", False)
-    s, o = mk(pkg, oracle, sc, False)
+    s, o = mk(pkg, oracle, sc, False, gather=variant)
     base, q = params_pair(pkg, oracle, side=side)
     sizes = set()
     for frame in range(6):
@@ -145,9 +153,10 @@ def test_moving_box_bit_exact(pkg, oracle):
         assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
 
 
-def test_edge_cases_bit_exact(pkg, oracle):
+def test_edge_cases_bit_exact(pkg, oracle, variant):
     p, q = params_pair(pkg, oracle)
     s = pkg.Solver(h=0.1)
+    s.set_option("gather", variant)
     # empty: "Particles depleted" (ompsph.hpp:122-126) — a no-op, not an error
     z = dict(id=np.zeros(0, np.uint64), type=np.zeros(0, np.uint8), mass=np.zeros(0, np.float32),
              pos=np.zeros((0, 3), np.float32), vel=np.zeros((0, 3), np.float32), colour=np.zeros((0, 4), np.float32))
@@ -180,14 +189,14 @@ def test_edge_cases_bit_exact(pkg, oracle):
         assert_state_equal(g, w, f"ragged frame {frame}")
 
 
-def test_obstacles_and_wells_bit_exact(pkg, oracle):
+def test_obstacles_and_wells_bit_exact(pkg, oracle, variant):
     """Obstacles follow the OpenCL backend (ocl/oclsph.cpp:66-69): fixed, lambda = 0, still
     neighbours.  Wells: ompsph.hpp:141-148."""
     sc, side = get_scene(pkg, "cubes1024", False)
     sc = {k: v.copy() for k, v in sc.items()}
     sc["type"][::7] = 1
     wells = [[300.0, 100.0, 300.0, 5000.0], [700.0, 50.0, 650.0, -2000.0]]
-    s, o = mk(pkg, oracle, sc, False)
+    s, o = mk(pkg, oracle, sc, False, gather=variant)
     p, q = params_pair(pkg, oracle, side=side, wells=wells)
     for frame in range(3):
         s.step(p)
@@ -198,6 +207,23 @@ def test_obstacles_and_wells_bit_exact(pkg, oracle):
     assert obs.sum() > 100
     orig = by_id(sc)
     assert np.array_equal(g["pos"][obs], orig["pos"][obs]) and np.array_equal(g["vel"][obs], orig["vel"][obs])
+
+
+def test_tile_overflow_falls_back_bit_exact(pkg, oracle):
+    """A brick whose halo holds more records than the LDS tile takes the in-kernel global walk;
+    neighbours of that brick stay tiled.  5000 particles inside 3x3x3 cells force it."""
+    rng = np.random.default_rng(11)
+    pile = (rng.random((5000, 3)) * 140 + 430).astype(np.float32)
+    far = (rng.random((3000, 3)) * 900 + 50).astype(np.float32)
+    pos = np.concatenate([pile, far])
+    n = len(pos)
+    sc = dict(id=np.arange(n, dtype=np.uint64), type=np.zeros(n, np.uint8), mass=np.ones(n, np.float32), pos=pos,
+              vel=np.zeros((n, 3), np.float32), colour=rng.random((n, 4)).astype(np.float32))
+    s, o = mk(pkg, oracle, sc, False, gather=2)
+    p, q = params_pair(pkg, oracle, iteration=2)
+    s.step(p)
+    o.step(q)
+    assert_state_equal(s.download(), o.get_particles())
 
 
 @pytest.mark.parametrize("iteration", [0, 1, 6])
