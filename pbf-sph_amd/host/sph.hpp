@@ -18,6 +18,7 @@
 #include <filesystem>
 #include <fstream>
 #include <iostream>
+#include <limits>
 #include <optional>
 #include <string>
 #include <tuple>
@@ -227,6 +228,7 @@ void save(const Result<T, N, V> &result, const std::vector<Particle<T, N, V>> &p
     ply << "ply\nformat ascii 1.0\nelement vertex " << particles.size()
         << "\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\n"
            "property uchar blue\nend_header\n";
+    ply.precision(std::numeric_limits<N>::max_digits10);
     auto u8 = [](N c) { return int(std::min(N(255), std::max(N(0), c * N(255)))); };
     for (const auto &p : particles)
       ply << p.position.x << ' ' << p.position.y << ' ' << p.position.z << ' ' << u8(p.colour.x) << ' '
