@@ -76,7 +76,6 @@ template <typename N> struct StepConsts {
   uint32_t tableN;  // Morton(extent) (sph.hpp:240)
   uint32_t nWells;
   uint32_t hasObstacles;
-  uint32_t probe;  // diagnostics only (env PBF_PROBE): 1 = loads without pair math, 2 = pair math without loads
 };
 
 }  // namespace pbf

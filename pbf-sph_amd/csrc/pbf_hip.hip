@@ -66,8 +66,8 @@ struct pbf_ctx {
   DevBuf bricks, brickCtl;  // non-empty brick list; brickCtl = {nActive, ticket[kTickets]}
   uint32_t gatherSeq = 0;   // which ticket word the next persistent gather launch uses
   int numCUs = 256;
-  uint32_t probe = 0;       // env PBF_PROBE (diagnostics, see StepConsts::probe)
-  int gatherKind = 0;       // 0 = global walk (k_gather_global), 1 = filtered lists, 2 = persistent LDS bricks
+  uint32_t padLds = 0;      // option "pad_lds": occupancy limiter for k_gather_global
+  int gatherKind = 1;       // 0 = global walk (k_gather_global), 1 = filtered lists (default), 2 = persistent LDS bricks
   uint32_t tileCap = 0, listMax = 0;  // 0 = defaults (env PBF_TILE_CAP / PBF_LIST_MAX override)
   size_t tableCap = 0;   // entries allocated in count/table
   uint32_t tableN = 0;
@@ -187,7 +187,6 @@ template <typename N> int make_consts(pbf_ctx *ctx, const pbf_params *p, StepCon
   c.n = uint32_t(ctx->n);
   c.nWells = uint32_t(p->n_wells > 0 ? p->n_wells : 0);
   c.hasObstacles = ctx->hasObstacles ? 1u : 0u;
-  c.probe = ctx->probe;
   ctx->tableN = c.tableN;
   return PBF_OK;
 }
@@ -354,16 +353,20 @@ template <typename N, typename Op> int launch_gather(pbf_ctx *ctx, const StepCon
   const uint32_t *key = ctx->key[ctx->cur].as<const uint32_t>();
   const uint32_t *table = ctx->table.as<const uint32_t>();
   if ((ctx->desc.flags & PBF_FLAG_NO_LDS) || ctx->gatherKind == 0) {
-    hipLaunchKernelGGL((k_gather_global<N, Op>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table);
+    // `padLds` bytes of unused dynamic LDS cap the workgroups per CU: fewer resident waves keep the
+    // 32 KiB L1 from thrashing on the gather's working set (each wave touches ~9 cache lines per load)
+    hipLaunchKernelGGL((k_gather_global<N, Op>), grid_for(ctx->n), dim3(BLOCK), ctx->padLds, ctx->stream, c, args, key,
+                       table);
     LAUNCH_CHECK(ctx);
     return PBF_OK;
   }
   if (ctx->gatherKind == 1) {
-    switch (ctx->listMax ? ctx->listMax : 32u) {
-      case 16: hipLaunchKernelGGL((k_gather_lists<N, Op, 16>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
+    switch (ctx->listMax ? ctx->listMax : 16u) {
+      case 12: hipLaunchKernelGGL((k_gather_lists<N, Op, 12>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
       case 24: hipLaunchKernelGGL((k_gather_lists<N, Op, 24>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
       case 48: hipLaunchKernelGGL((k_gather_lists<N, Op, 48>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
-      default: hipLaunchKernelGGL((k_gather_lists<N, Op, 32>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
+      case 32: hipLaunchKernelGGL((k_gather_lists<N, Op, 32>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
+      default: hipLaunchKernelGGL((k_gather_lists<N, Op, 16>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
     }
     LAUNCH_CHECK(ctx);
     return PBF_OK;
@@ -550,7 +553,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   if (n == "list_max") ctx->listMax = uint32_t(value);
   else if (n == "gather") ctx->gatherKind = int(value);
   else if (n == "tile_cap") ctx->tileCap = uint32_t(value);
-  else if (n == "probe") ctx->probe = uint32_t(value);
+  else if (n == "pad_lds") ctx->padLds = uint32_t(value);
   else return fail(ctx, PBF_ERR_INVALID, "unknown option " + n);
   return PBF_OK;
 }
@@ -596,7 +599,6 @@ int pbf_create(const pbf_desc *desc, pbf_ctx **out) {
   ctx->fast = (desc->flags & PBF_FLAG_FAST_MATH) != 0;
   ctx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = std::getenv("PBF_TILE_CAP")) ctx->tileCap = uint32_t(std::atoi(e));
-  if (const char *e = std::getenv("PBF_PROBE")) ctx->probe = uint32_t(std::atoi(e));
   if (const char *e = std::getenv("PBF_GATHER")) ctx->gatherKind = std::atoi(e);
   if (const char *e = std::getenv("PBF_LIST_MAX")) ctx->listMax = uint32_t(std::atoi(e));
   if ((e = hipSetDevice(ctx->device)) != hipSuccess) {

@@ -247,6 +247,30 @@ __device__ inline void for_each_candidate(uint32_t key, const uint32_t *__restri
     }
 }
 
+// Same walk, candidates handed over two at a time (f2(b, b + 1)) so that their pair terms share a
+// basic block; visiting order is unchanged.
+template <typename F1, typename F2>
+__device__ inline void for_each_candidate2(uint32_t key, const uint32_t *__restrict__ table, uint32_t tableN, F1 &&f1,
+                                           F2 &&f2) {
+  const Neigh nb = neigh_codes(key);
+#pragma unroll 1
+  for (int dz = 0; dz < 3; ++dz)
+#pragma unroll 1
+    for (int dy = 0; dy < 3; ++dy) {
+      const uint32_t yz = nb.ys[dy] | nb.zs[dz];
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const uint32_t code = nb.xs[dx] | yz;
+        if (code >= tableN) continue;
+        const uint32_t start = table[code];
+        const uint32_t end = (code + 1u) < tableN ? table[code + 1u] : start;
+        uint32_t b = start;
+        for (; b + 1u < end; b += 2u) f2(b, b + 1u);
+        if (b < end) f1(b);
+      }
+    }
+}
+
 // Pair terms shared by lambda / delta.  PRECISE follows the oracle's operation order with IEEE
 // sqrt and divide; FAST uses one v_rsq (the reference's own builds are -Ofast / native_divide).
 template <typename N, bool FAST> struct PairGeom {
@@ -326,6 +350,7 @@ template <typename N> struct DiffuseOp {
     mx += cb.x, my += cb.y, mz += cb.z, mw += cb.w;
     ++nn;
   }
+  __device__ void add_bf(const StepConsts<N> &c, const Src &cb) { add(c, cb); }
   __device__ void end(const StepConsts<N> &c, const Args &a, uint32_t i) {
     vec4<N> out = ca;
     if (nn != 0) {
@@ -368,7 +393,7 @@ template <typename N, bool FAST> struct LambdaOp {
   }
   __device__ void add(const StepConsts<N> &c, const Src &pb) {
     const auto g = pair_geom<N, FAST>(pa, pb, c.h);
-    if (g.inSpiky) {
+    if (g.inSpiky) {  // wave-level skip: lanes of one cell test the same candidate, so whole waves often miss
       const N s = c.spikyFactor * g.hr2_over_r;
       gx += (g.dx * s) * N(RHO_RECIP), gy += (g.dy * s) * N(RHO_RECIP), gz += (g.dz * s) * N(RHO_RECIP);
     }
@@ -376,6 +401,18 @@ template <typename N, bool FAST> struct LambdaOp {
       const N d = (c.h * c.h) - g.r * g.r;
       rho += mass * (c.poly6Factor * (d * d * d));
     }
+  }
+  __device__ void add_bf(const StepConsts<N> &c, const Src &pb) {
+    // branch-free form for the list drain: two consecutive calls form one basic block and their long
+    // sqrt / divide chains interleave.  An excluded pair contributes exactly +0 (a select, never a
+    // multiply: r = 0 makes hr2_over_r infinite), which leaves every partial sum bit-identical.
+    const auto g = pair_geom<N, FAST>(pa, pb, c.h);
+    const N s = c.spikyFactor * g.hr2_over_r;
+    const N tx = (g.dx * s) * N(RHO_RECIP), ty = (g.dy * s) * N(RHO_RECIP), tz = (g.dz * s) * N(RHO_RECIP);
+    gx += g.inSpiky ? tx : N(0), gy += g.inSpiky ? ty : N(0), gz += g.inSpiky ? tz : N(0);
+    const N d = (c.h * c.h) - g.r * g.r;
+    const N w = mass * (c.poly6Factor * (d * d * d));
+    rho += g.inH ? w : N(0);
   }
   __device__ void end(const StepConsts<N> &, const Args &a, uint32_t i) {
     const N norm2 = gx * gx + gy * gy + gz * gz;
@@ -419,6 +456,19 @@ template <typename N, bool FAST> struct DeltaOp {
       ax += (g.dx * s) * factor, ay += (g.dy * s) * factor, az += (g.dz * s) * factor;
     }
   }
+  __device__ void add_bf(const StepConsts<N> &c, const Src &pb) {
+    // branch-free like LambdaOp::add_bf; outside the spiky support the gradient is exactly zero, so
+    // corr / factor are irrelevant there and the select adds +0
+    const auto g = pair_geom<N, FAST>(pa, pb, c.h);
+    const N d = (c.h * c.h) - g.r * g.r;
+    const N q = (c.poly6Factor * (d * d * d)) / c.p6DeltaQ;
+    const N q2 = q * q;
+    const N corr = N(-CorrK) * (q2 * q2);  // pow(q, CorrN = 4) of ompsph.hpp:240
+    const N factor = (pa.w + pb.w + corr) / N(RHO);
+    const N s = c.spikyFactor * g.hr2_over_r;
+    const N tx = (g.dx * s) * factor, ty = (g.dy * s) * factor, tz = (g.dz * s) * factor;
+    ax += g.inSpiky ? tx : N(0), ay += g.inSpiky ? ty : N(0), az += g.inSpiky ? tz : N(0);
+  }
   __device__ void end(const StepConsts<N> &c, const Args &a, uint32_t i) {
     N x = (pa.x + ax) * c.scale, y = (pa.y + ay) * c.scale, z = (pa.z + az) * c.scale;
     x = min(c.maxB[0], max(c.minB[0], x));
@@ -436,22 +486,20 @@ __device__ inline void gather_one_global(const StepConsts<N> &c, const typename 
   Op op;
   if (!op.begin(c, args, i)) return;
   const typename Op::Src *src = Op::src(args);
-  if (c.probe == 0) {
+  if (Op::kNeedsCandidateType && c.hasObstacles) {
     for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) {
-      if (Op::kNeedsCandidateType && c.hasObstacles && args.type[b] == 1) return;
-      op.add(c, src[b]);
+      if (args.type[b] != 1) op.add(c, src[b]);
     });
-  } else if (c.probe == 1) {  // diagnostic: memory side only
-    N acc = 0;
-    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { acc += src[b].x; });
-    if (acc == N(12345.678)) op.add(c, src[i]);
-  } else {  // diagnostic: pair math only (candidate synthesised from the loop index, no candidate loads)
-    const typename Op::Src me = src[i];
-    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) {
-      typename Op::Src f = me;
-      f.x += N(b & 63u) * N(0.002), f.y += N((b >> 6) & 63u) * N(0.001);
-      op.add(c, f);
-    });
+  } else if (Op::kFilter) {  // lambda / delta: the branchy pair terms skip whole waves, keep one per trip
+    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { op.add(c, src[b]); });
+  } else {
+    for_each_candidate2(
+        key[i], table, c.tableN, [&](uint32_t b) { op.add(c, src[b]); },
+        [&](uint32_t b0, uint32_t b1) {
+          const typename Op::Src p0 = src[b0], p1 = src[b1];
+          op.add(c, p0);
+          op.add(c, p1);
+        });
   }
   op.end(c, args, i);
 }
@@ -674,7 +722,7 @@ __global__ __launch_bounds__(THREADS) void k_gather_bricks(StepConsts<N> c, type
       if constexpr (Op::kFilter) {
         uint32_t nl = 0;
         auto flush = [&]() {
-          for (uint32_t q = 0; q < nl; ++q) op.add(c, tile[list[q * THREADS + tid]]);
+          for (uint32_t q = 0; q < nl; ++q) op.add_bf(c, tile[list[q * THREADS + tid]]);
           nl = 0;
         };
 #pragma unroll 1
@@ -710,11 +758,11 @@ __global__ __launch_bounds__(THREADS) void k_gather_bricks(StepConsts<N> c, type
 
 // ------------------------------------------------------------------------------------------------
 // Gather kernel D — one lane per particle, candidates from global memory (L1/L2), two phases:
-//   A  every lane walks its 27 cell ranges as ONE flattened loop (wave-uniform trip count = the
-//      longest lane, not the sum of per-cell maxima) and applies the conservative maybe_within_h
-//      filter; survivors' global indices go to a per-lane list in LDS ([slot][thread], 4-byte);
-//   B  whenever any lane's list is full — and once at the end — ALL lanes drain their lists through
-//      the exact pair terms, in visiting order.  Rejected candidates contribute exactly +0, so
+//   A  every lane walks its 27 cell ranges like kernel A but only applies the conservative
+//      maybe_within_h filter (3 sub + 3 fma + cmp); survivors' global indices go to a per-lane list
+//      in LDS ([slot][thread], 4-byte);
+//   B  whenever an active lane's list is full — and once at the end — the lanes drain their lists
+//      through the exact pair terms (IEEE sqrt / divide), in visiting order.  Rejected candidates contribute exactly +0, so
 //      results are bit-identical to the plain walk.
 // No tiles, no bricks: occupancy is set by the list alone (LMAX x 1 KiB per 256 threads), and sparse
 // splash regions cost the same per particle as the dense column.
@@ -735,44 +783,32 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
   __shared__ uint32_t list[(Op::kFilter ? LMAX : 1) * BLOCK];
   const uint32_t tid = threadIdx.x;
   const uint32_t i = blockIdx.x * BLOCK + tid;
-  Op op;
-  const bool live = i < c.n && op.begin(c, args, i);
-  const typename Op::Src *src = Op::src(args);
-  const uint32_t k = live ? key[i] : 0u;
-  const uint32_t xm = k & MORTON_X, ym = k & MORTON_Y, zm = k & MORTON_Z;
-  uint32_t ci = live ? 0u : 27u, j = 0, e = 0, nl = 0;
-  auto drain = [&]() {
-#pragma unroll 2
-    for (uint32_t q = 0; q < nl; ++q) op.add(c, src[list[q * BLOCK + tid]]);
-    nl = 0;
-  };
-  for (;;) {
-    while (j == e && ci < 27u) {  // next non-empty cell range (sph.hpp:205-208)
-      const uint32_t code = neighbour_code(xm, ym, zm, ci);
-      ++ci;
-      if (code < c.tableN) {
-        j = table[code];
-        e = (code + 1u) < c.tableN ? table[code + 1u] : j;
-      }
-    }
-    const bool has = j < e;
-    if (!__any(has)) break;  // wave-uniform: every lane has exhausted its 27 cells
-    if (has) {
-      if constexpr (Op::kFilter) {
-        const bool hit = op.near(c, src[j]);
-        list[nl * BLOCK + tid] = j;  // branch-free append: the slot is kept only on a hit
-        nl += hit ? 1u : 0u;
-      } else {
-        if (!(Op::kNeedsCandidateType && c.hasObstacles && args.type[j] == 1)) op.add(c, src[j]);
-      }
-      ++j;
-    }
-    if constexpr (Op::kFilter) {
-      if (__any(nl == uint32_t(LMAX))) drain();  // all lanes drain together, each in its own order
-    }
+  if (i >= c.n) return;
+  if constexpr (!Op::kFilter) {  // diffuse has no distance test: nothing to filter, plain (2-way) walk
+    gather_one_global<N, Op>(c, args, key, table, i);
+    return;
   }
-  if constexpr (Op::kFilter) drain();
-  if (live) op.end(c, args, i);
+  Op op;
+  if (!op.begin(c, args, i)) return;
+  const typename Op::Src *src = Op::src(args);
+  {
+    uint32_t nl = 0;
+    auto drain = [&]() {
+#pragma unroll 2
+      for (uint32_t q = 0; q < nl; ++q) op.add_bf(c, src[list[q * BLOCK + tid]]);
+      nl = 0;
+    };
+    // same walk as kernel A (lanes of one cell stay in lockstep => their candidate loads coalesce);
+    // phase A only filters, phase B (drain) runs the exact pair terms for the survivors, in order
+    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) {
+      const bool hit = op.near(c, src[b]);
+      list[nl * BLOCK + tid] = b;  // branch-free append: the slot is kept only on a hit
+      nl += hit ? 1u : 0u;
+      if (__any(nl == uint32_t(LMAX))) drain();  // every lane active here drains together
+    });
+    drain();
+  }
+  op.end(c, args, i);
 }
 
 // ------------------------------------------------------------------------------------------------
