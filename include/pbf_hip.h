@@ -134,6 +134,37 @@ int pbf_grid_extent(const pbf_ctx *ctx, uint64_t extent[3], double min_extent[3]
 int pbf_stage_times(pbf_ctx *ctx, const char **names, double *mean_ms, uint64_t *calls, int cap);
 int pbf_reset_stage_times(pbf_ctx *ctx);
 
+/* ---- multi-GPU: slab decomposition along x (no reference counterpart: it is single-device) ------
+ * One process per GPU.  Every rank uses the GLOBAL grid (same pbf_params bounds), owns the cell columns
+ * [xlo, xhi) and keeps a one-cell layer of COPIES ("ghosts", type bit PBF_TYPE_GHOST) of its x-neighbours'
+ * boundary columns.  The library selects / packs / appends / unpacks on the device; the caller moves the
+ * wire buffers (device pointers) with RCCL — e.g. torch.distributed "nccl" send/recv over xGMI — see
+ * pbf-sph_amd/slab.py for the per-step protocol:
+ *   predict -> migrate -> add_migrants -> ghosts -> add_ghosts -> sort -> diffuse ->
+ *   K x { lambda -> pack/exchange/unpack -> delta -> pack/exchange/unpack } -> finalise -> finish */
+enum { PBF_TYPE_GHOST = 2 };
+enum { PBF_REC_MIGRANT = 0, PBF_REC_GHOST = 1, PBF_REC_FIELD = 2 };
+typedef struct pbf_slab_cut {
+  uint32_t xlo, xhi;           /* owned cell columns [xlo, xhi), grid coordinates of pbf_grid_extent */
+  int32_t has_left, has_right; /* is there a rank on that side */
+} pbf_slab_cut;
+int pbf_reserve(pbf_ctx *ctx, size_t capacity); /* room for migrants + copies; call before pbf_upload */
+size_t pbf_slab_record_bytes(const pbf_ctx *ctx, int kind);
+/* after pbf_stage_predict: compact the particles that stay, pack the leavers; counts[2] = records for left / right */
+int pbf_slab_migrate(pbf_ctx *ctx, const pbf_slab_cut *cut, void *send_left, void *send_right, uint32_t cap_records,
+                     uint32_t counts[2]);
+int pbf_slab_add_migrants(pbf_ctx *ctx, const void *recv_left, uint32_t n_left, const void *recv_right, uint32_t n_right);
+/* pack copies of the first / last owned column; remembers the sources for pbf_slab_pack */
+int pbf_slab_ghosts(pbf_ctx *ctx, const pbf_slab_cut *cut, void *send_left, void *send_right, uint32_t cap_records,
+                    uint32_t counts[2]);
+/* append the neighbours' copies and rebuild the cell histogram; pbf_stage_sort comes next */
+int pbf_slab_add_ghosts(pbf_ctx *ctx, const void *recv_left, uint32_t n_left, const void *recv_right, uint32_t n_right);
+/* after each lambda / delta launch: owners' {pStar, lambda} -> wire, wire -> copies (PBF_REC_FIELD records) */
+int pbf_slab_pack(pbf_ctx *ctx, void *send_left, void *send_right);
+int pbf_slab_unpack(pbf_ctx *ctx, const void *recv_left, const void *recv_right);
+int pbf_slab_finish(pbf_ctx *ctx); /* after finalise: drop the copies */
+size_t pbf_owned_count(const pbf_ctx *ctx);
+
 /* ---- scene factory (sph.hpp:127-186; dam-break: SURVEY.md §8d) — host only, no GPU needed -- */
 size_t pbf_scene_cubes(int fp64, size_t count, uint64_t *id, uint8_t *type, void *mass, void *pos, void *vel,
                        void *colour);

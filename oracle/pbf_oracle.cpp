@@ -201,7 +201,7 @@ template <typename N> struct Oracle final : pbf_oracle {
     const N h = N(c.h), dt = N(c.dt), scale = N(c.scale);
     const V3<N> force{N(c.constant_force[0]), N(c.constant_force[1]), N(c.constant_force[2])};
     foreach_1d(c.threads, cnt, [&](size_t i) {
-      if (type[i] == 1) {
+      if (type[i] & 1) {
         pStar[i] = pos[i] / scale;
       } else {
         V3<N> combinedForce = mass[i] * force;
@@ -282,11 +282,11 @@ template <typename N> struct Oracle final : pbf_oracle {
     const size_t cnt = n();
     const N t = N(c.dt) / N(750.0);
     auto body = [&](size_t a, const std::vector<V4<N>> &in, std::vector<V4<N>> &out) {
-      if (type[a] == 1) return;
+      if (type[a] != 0) return;  // obstacle, or a ghost copy (bit 1) owned by another slab (tests of the slab driver)
       int nNeighbours = 0;
       V4<N> mixture{N(0), N(0), N(0), N(0)};
       foreach_grid(zIndex[a], [&](size_t b) {
-        if (type[b] != 1) {
+        if (!(type[b] & 1)) {
           mixture = {mixture.x + in[b].x, mixture.y + in[b].y, mixture.z + in[b].z, mixture.w + in[b].w};
           nNeighbours++;
         }
@@ -318,8 +318,8 @@ template <typename N> struct Oracle final : pbf_oracle {
     const N Poly6Factor = poly6Factor(h);
     const N SpikyKernelFactor = spikyKernelFactor(h);
     foreach_1d(c.threads, cnt, [&](size_t a) {
-      if (type[a] == 1) {
-        lambda[a] = 0;
+      if (type[a] != 0) {
+        if (type[a] & 1) lambda[a] = 0;  // a ghost copy keeps the lambda its owner sent
         return;
       }
       V3<N> norm2V{N(0), N(0), N(0)};
@@ -347,7 +347,7 @@ template <typename N> struct Oracle final : pbf_oracle {
     const V3<N> minB{N(c.min_bound[0]), N(c.min_bound[1]), N(c.min_bound[2])};
     const V3<N> maxB{N(c.max_bound[0]), N(c.max_bound[1]), N(c.max_bound[2])};
     auto body = [&](size_t a, const std::vector<V3<N>> &in, std::vector<V3<N>> &out) {
-      if (type[a] == 1) return;
+      if (type[a] != 0) return;
       V3<N> deltaPAcc{N(0), N(0), N(0)};
       foreach_grid(zIndex[a], [&](size_t b) {
         const N r = distance(in[a], in[b]);
@@ -434,7 +434,7 @@ template <typename N> struct Oracle final : pbf_oracle {
     const size_t cnt = n();
     const N dt = N(c.dt), scale = N(c.scale);
     foreach_1d(c.threads, cnt, [&](size_t a) {
-      if (type[a] == 1) return;
+      if (type[a] != 0) return;
       const V3<N> deltaX = pStar[a] - pos[a] / scale;
       pos[a] = pStar[a] * scale;
       vel[a] = (deltaX * (N(1) / dt) + vel[a]) * N(VD);
@@ -680,6 +680,17 @@ void pbf_oracle_motion_offset(int fp64, uint64_t frame, double out[3]) {
   out[0] = fp64 ? ox : double(float(ox));
   out[1] = 0.0;
   out[2] = fp64 ? oz : double(float(oz));
+}
+
+int pbf_oracle_set_scratch(pbf_oracle *o, const uint64_t *keys, const void *pstar, const void *lambda) {
+  return dispatch(o, [&](auto &s) {
+    using N = std::decay_t<decltype(s.mass[0])>;
+    const size_t n = s.n();
+    if (keys) s.zIndex.assign(keys, keys + n);
+    if (pstar) std::memcpy(s.pStar.data(), pstar, n * 3 * sizeof(N));
+    if (lambda) std::memcpy(s.lambda.data(), lambda, n * sizeof(N));
+    return 0;
+  });
 }
 
 void pbf_oracle_set_pow4(pbf_oracle *o, int on) {

@@ -108,6 +108,11 @@ size_t pbf_oracle_scene_dambreak(int fp64, size_t nominal, uint64_t *id, void *m
 /* applyMotionSinXCosZ (sph.hpp:147-158): offset added to min/max bound at a frame, computed in float */
 void pbf_oracle_motion_offset(int fp64, uint64_t frame, double out[3]);
 
+/* Overwrite the scratch state (same order as the particles); NULL = leave.  Used by the tests of the
+ * slab driver, which re-assemble owned particles + ghost copies (type bit 1 = ghost: a candidate that is
+ * never updated locally) between stages. */
+int pbf_oracle_set_scratch(pbf_oracle *, const uint64_t *keys, const void *pstar, const void *lambda);
+
 /* Sensitivity probe (tests only): evaluate pow(q, CorrN) as (q*q)*(q*q), the device's form, instead
  * of the reference's std::pow (ompsph.hpp:240).  Default off = reference semantics. */
 void pbf_oracle_set_pow4(pbf_oracle *, int on);

@@ -16,6 +16,7 @@ from .capi import (  # noqa: F401
     LIB_PATH,
     Params,
     PbfError,
+    SlabCut,
     Solver,
     apply_motion,
     build,

@@ -63,6 +63,10 @@ class Params(C.Structure):
         return self
 
 
+class SlabCut(C.Structure):
+    _fields_ = [("xlo", C.c_uint32), ("xhi", C.c_uint32), ("has_left", C.c_int32), ("has_right", C.c_int32)]
+
+
 class AosLayout(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("stride", "off_id", "off_type", "off_mass", "off_pos", "off_vel",
                                           "off_colour")]
@@ -105,6 +109,16 @@ _SIGS = {
     "pbf_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                   C.c_int]),
     "pbf_reset_stage_times": (C.c_int, [C.c_void_p]),
+    "pbf_reserve": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "pbf_slab_record_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "pbf_slab_migrate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "pbf_slab_add_migrants": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "pbf_slab_ghosts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "pbf_slab_add_ghosts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "pbf_slab_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pbf_slab_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pbf_slab_finish": (C.c_int, [C.c_void_p]),
+    "pbf_owned_count": (C.c_size_t, [C.c_void_p]),
     "pbf_scene_cubes": (C.c_size_t, [C.c_int, C.c_size_t] + [C.c_void_p] * 6),
     "pbf_scene_dambreak": (C.c_size_t, [C.c_int, C.c_size_t] + [C.c_void_p] * 6 + [C.POINTER(C.c_double)]),
     "pbf_apply_motion": (None, [C.c_int, C.POINTER(Params), C.c_uint64, C.POINTER(Params)]),

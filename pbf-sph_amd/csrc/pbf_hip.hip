@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "pbf_kernels.hpp"
+#include "pbf_slab.hpp"
 
 using namespace pbf;
 
@@ -63,6 +64,11 @@ struct pbf_ctx {
   DevBuf pos4[2], vel4[2], col4[2], id[2], type[2], key[2];
   DevBuf pstar[3];       // [0],[1]: sort ping-pong partner of set 0/1 ; [2]: Jacobi partner
   DevBuf count, table, blockSums, permTmp, wells, staging;
+  // slab decomposition (pbf_slab_*): bookkeeping of what was sent / received this step
+  DevBuf slotOf, selCounts, selTotals, ghostSrcL, ghostSrcR;
+  bool slabActive = false, realObstacles = false;
+  size_t reserve = 0;        // pbf_reserve: capacity kept for migrants and ghost copies
+  uint32_t nOwned = 0, sentL = 0, sentR = 0, gotL = 0, gotR = 0;
   DevBuf bricks, brickCtl;  // non-empty brick list; brickCtl = {nActive, ticket[kTickets]}
   uint32_t gatherSeq = 0;   // which ticket word the next persistent gather launch uses
   int numCUs = 256;
@@ -117,6 +123,7 @@ int ensure(pbf_ctx *ctx, DevBuf &b, size_t bytes, bool zero = false) {
 template <typename N> size_t vsz() { return sizeof(vec4<N>); }
 
 int ensure_particles(pbf_ctx *ctx, size_t n) {
+  n = std::max(n, ctx->reserve);
   if (ctx->cap >= n) return PBF_OK;
   const size_t v = ctx->fp64 ? sizeof(double4) : sizeof(float4);
   for (int s = 0; s < 2; ++s) {
@@ -130,6 +137,7 @@ int ensure_particles(pbf_ctx *ctx, size_t n) {
   for (int s = 0; s < 3; ++s)
     if (int rc = ensure(ctx, ctx->pstar[s], n * v)) return rc;
   if (int rc = ensure(ctx, ctx->permTmp, n * 4)) return rc;
+  if (int rc = ensure(ctx, ctx->slotOf, n * 4)) return rc;
   ctx->cap = n;
   return PBF_OK;
 }
@@ -328,7 +336,8 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
   hipLaunchKernelGGL(k_scatter_slots, grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c.n, c.tableN,
                      ctx->key[s].as<const uint32_t>(), table, count, ctx->permTmp.as<uint32_t>());
   hipLaunchKernelGGL((k_rank_move<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c.n, c.tableN,
-                     ctx->permTmp.as<const uint32_t>(), table, arrays<N>(ctx, s, s), arrays<N>(ctx, d, d));
+                     ctx->permTmp.as<const uint32_t>(), table, arrays<N>(ctx, s, s), arrays<N>(ctx, d, d),
+                     ctx->slabActive ? ctx->slotOf.as<uint32_t>() : nullptr);
   {  // list of non-empty bricks for the persistent gather kernels (+ fresh tickets)
     const uint32_t home = Brick<kBrickZ>::HOME, nBricks = (c.tableN + home - 1) / home;
     HIPCHK(ctx, hipMemsetAsync(ctx->brickCtl.p, 0, (kTickets + 1) * 4, ctx->stream));
@@ -500,8 +509,9 @@ int upload_impl(pbf_ctx *ctx, size_t n, const uint64_t *id, const uint8_t *type,
     P[i] = make_vec4<N>(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], mass[i]);
     V[i] = make_vec4<N>(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2], N(0));
     C[i] = make_vec4<N>(colour[4 * i], colour[4 * i + 1], colour[4 * i + 2], colour[4 * i + 3]);
-    if (type[i] == PBF_TYPE_OBSTACLE) ctx->hasObstacles = true;
+    if (type[i] & PBF_TYPE_OBSTACLE) ctx->hasObstacles = true;
   }
+  ctx->realObstacles = ctx->hasObstacles;
   HIPCHK(ctx, hipMemcpyAsync(ctx->pos4[0].p, P.data(), n * sizeof(vec4<N>), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->vel4[0].p, V.data(), n * sizeof(vec4<N>), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->col4[0].p, C.data(), n * sizeof(vec4<N>), hipMemcpyHostToDevice, ctx->stream));
@@ -632,7 +642,8 @@ void pbf_destroy(pbf_ctx *ctx) {
   DevBuf *all[] = {&ctx->pos4[0], &ctx->pos4[1], &ctx->vel4[0], &ctx->vel4[1], &ctx->col4[0],  &ctx->col4[1],
                    &ctx->id[0],   &ctx->id[1],   &ctx->type[0], &ctx->type[1], &ctx->key[0],   &ctx->key[1],
                    &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2], &ctx->count, &ctx->table,   &ctx->blockSums,
-                   &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl};
+                   &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl,
+                   &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR};
   for (DevBuf *b : all)
     if (b->p) (void)hipFree(b->p);
   if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
@@ -810,5 +821,198 @@ int pbf_reset_stage_times(pbf_ctx *ctx) {
   for (int k = 0; k < ST_COUNT; ++k) ctx->stageMs[k] = 0, ctx->stageCalls[k] = 0;
   return PBF_OK;
 }
+
+}  // extern "C"
+
+// ================================================================================================
+// Slab decomposition entry points (include/pbf_hip.h "multi-GPU").  The caller (one process per
+// GPU) owns the wire buffers and moves them with RCCL (torch.distributed "nccl" send/recv over
+// xGMI); this library only selects, packs, appends and unpacks on the device.
+// ================================================================================================
+namespace {
+
+template <typename N, int MODE>
+int run_select(pbf_ctx *ctx, const pbf_slab_cut *cut, void *sendL, void *sendR, uint32_t cap, uint32_t totals[3]) {
+  const uint32_t n = uint32_t(ctx->n);
+  const uint32_t nb = (n + SEL_TILE - 1) / SEL_TILE;
+  if (int rc = ensure(ctx, ctx->selCounts, size_t(3) * std::max(nb, 1u) * 4)) return rc;
+  if (int rc = ensure(ctx, ctx->selTotals, 16)) return rc;
+  if (int rc = ensure(ctx, ctx->ghostSrcL, size_t(std::max(cap, 1u)) * 4)) return rc;
+  if (int rc = ensure(ctx, ctx->ghostSrcR, size_t(std::max(cap, 1u)) * 4)) return rc;
+  totals[0] = totals[1] = totals[2] = 0;
+  if (n == 0) return PBF_OK;
+  SlabCut s{cut->xlo, cut->xhi, cut->has_left ? 1u : 0u, cut->has_right ? 1u : 0u};
+  const int a = ctx->cur, b = 1 - a;
+  uint32_t *counts = ctx->selCounts.as<uint32_t>(), *tot = ctx->selTotals.as<uint32_t>();
+  hipLaunchKernelGGL((k_sel_count<MODE>), dim3(nb), dim3(BLOCK), 0, ctx->stream, n, s, ctx->key[a].as<const uint32_t>(),
+                     ctx->type[a].as<const uint8_t>(), nb, counts);
+  hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(BLOCK), 0, ctx->stream, nb, counts, tot);
+  hipLaunchKernelGGL((k_sel_emit<N, MODE>), dim3(nb), dim3(BLOCK), 0, ctx->stream, n, s, arrays<N>(ctx, a, ctx->pcur),
+                     arrays<N>(ctx, b, b), nb, counts, sendL, sendR, cap, ctx->ghostSrcL.as<uint32_t>(),
+                     ctx->ghostSrcR.as<uint32_t>());
+  LAUNCH_CHECK(ctx);
+  HIPCHK(ctx, hipMemcpyAsync(totals, tot, 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the caller needs the counts to size its sends
+  return PBF_OK;
+}
+
+template <typename N> int slab_migrate(pbf_ctx *ctx, const pbf_slab_cut *cut, void *sL, void *sR, uint32_t cap, uint32_t out[2]) {
+  if (int rc = drop_histogram(ctx)) return rc;  // predict's histogram describes the pre-migration set
+  uint32_t t[3];
+  if (int rc = run_select<N, SEL_MIGRATE>(ctx, cut, sL, sR, cap, t)) return rc;
+  if (t[1] > cap || t[2] > cap) return fail(ctx, PBF_ERR_INVALID, "migrant buffer too small");
+  if (ctx->n) {
+    ctx->cur = 1 - ctx->cur;  // the keeps were compacted into the other array set
+    ctx->pcur = ctx->cur;
+  }
+  ctx->n = t[0];
+  ctx->nOwned = t[0];
+  ctx->sorted = false;
+  out[0] = t[1], out[1] = t[2];
+  return PBF_OK;
+}
+
+template <typename N> int slab_add_migrants(pbf_ctx *ctx, const void *rL, uint32_t nL, const void *rR, uint32_t nR) {
+  if (ctx->n + nL + nR > ctx->cap) return fail(ctx, PBF_ERR_INVALID, "particle capacity exceeded: call pbf_reserve");
+  if (nL + nR)
+    hipLaunchKernelGGL((k_append_migrants<N>), grid_for(nL + nR), dim3(BLOCK), 0, ctx->stream, uint32_t(ctx->n),
+                       static_cast<const MigrantRec<N> *>(rL), nL, static_cast<const MigrantRec<N> *>(rR), nR,
+                       arrays<N>(ctx, ctx->cur, ctx->pcur));
+  LAUNCH_CHECK(ctx);
+  ctx->n += nL + nR;
+  ctx->nOwned = uint32_t(ctx->n);
+  return PBF_OK;
+}
+
+template <typename N> int slab_ghosts(pbf_ctx *ctx, const pbf_slab_cut *cut, void *sL, void *sR, uint32_t cap, uint32_t out[2]) {
+  uint32_t t[3];
+  if (int rc = run_select<N, SEL_GHOST>(ctx, cut, sL, sR, cap, t)) return rc;
+  if (t[0] > cap || t[1] > cap) return fail(ctx, PBF_ERR_INVALID, "ghost buffer too small");
+  ctx->sentL = t[0], ctx->sentR = t[1];
+  out[0] = t[0], out[1] = t[1];
+  return PBF_OK;
+}
+
+template <typename N> int slab_add_ghosts(pbf_ctx *ctx, const void *rL, uint32_t nL, const void *rR, uint32_t nR) {
+  if (ctx->n + nL + nR > ctx->cap) return fail(ctx, PBF_ERR_INVALID, "particle capacity exceeded: call pbf_reserve");
+  if (nL + nR)
+    hipLaunchKernelGGL((k_append_ghosts<N>), grid_for(nL + nR), dim3(BLOCK), 0, ctx->stream, uint32_t(ctx->n),
+                       static_cast<const GhostRec<N> *>(rL), nL, static_cast<const GhostRec<N> *>(rR), nR,
+                       arrays<N>(ctx, ctx->cur, ctx->pcur));
+  ctx->gotL = nL, ctx->gotR = nR;
+  ctx->n += nL + nR;
+  if (nL + nR) ctx->hasObstacles = true;  // "special" particles exist: the kernels must look at type[]
+  // histogram of the re-assembled set (owned + copies) for the sort
+  if (ctx->n)
+    hipLaunchKernelGGL(k_count_keys, grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, uint32_t(ctx->n), ctx->tableN,
+                       ctx->key[ctx->cur].as<const uint32_t>(), ctx->count.as<uint32_t>());
+  LAUNCH_CHECK(ctx);
+  ctx->counted = true;
+  ctx->countedTableN = ctx->tableN;
+  ctx->slabActive = true;
+  return PBF_OK;
+}
+
+template <typename N> int slab_pack(pbf_ctx *ctx, void *sL, void *sR) {
+  const uint32_t m = ctx->sentL + ctx->sentR;
+  if (m)
+    hipLaunchKernelGGL((k_pack_field<N>), grid_for(m), dim3(BLOCK), 0, ctx->stream, ctx->sentL, ctx->sentR,
+                       ctx->ghostSrcL.as<const uint32_t>(), ctx->ghostSrcR.as<const uint32_t>(),
+                       ctx->slotOf.as<const uint32_t>(), ctx->pstar[ctx->pcur].as<const vec4<N>>(),
+                       static_cast<vec4<N> *>(sL), static_cast<vec4<N> *>(sR));
+  LAUNCH_CHECK(ctx);
+  return PBF_OK;
+}
+
+template <typename N> int slab_unpack(pbf_ctx *ctx, const void *rL, const void *rR) {
+  const uint32_t m = ctx->gotL + ctx->gotR;
+  if (m)
+    hipLaunchKernelGGL((k_unpack_field<N>), grid_for(m), dim3(BLOCK), 0, ctx->stream, ctx->nOwned, ctx->gotL, ctx->gotR,
+                       static_cast<const vec4<N> *>(rL), static_cast<const vec4<N> *>(rR),
+                       ctx->slotOf.as<const uint32_t>(), ctx->pstar[ctx->pcur].as<vec4<N>>());
+  LAUNCH_CHECK(ctx);
+  return PBF_OK;
+}
+
+template <typename N> int slab_finish(pbf_ctx *ctx) {
+  // drop the copies: the MIGRATE select with no neighbours keeps exactly the non-ghost particles
+  pbf_slab_cut none{0, 0xFFFFFFFFu, 0, 0};
+  uint32_t t[3];
+  const bool wasSorted = ctx->sorted;
+  if (int rc = run_select<N, SEL_MIGRATE>(ctx, &none, nullptr, nullptr, 0, t)) return rc;
+  if (ctx->n) {
+    ctx->cur = 1 - ctx->cur;
+    ctx->pcur = ctx->cur;
+  }
+  ctx->n = t[0];
+  ctx->nOwned = t[0];
+  ctx->sorted = false;
+  (void)wasSorted;
+  ctx->hasObstacles = ctx->realObstacles;
+  ctx->slabActive = false;
+  ctx->sentL = ctx->sentR = ctx->gotL = ctx->gotR = 0;
+  return PBF_OK;
+}
+
+int slab_check(pbf_ctx *ctx) {
+  if (!ctx) return PBF_ERR_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return PBF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pbf_reserve(pbf_ctx *ctx, size_t capacity) {
+  if (!ctx) return PBF_ERR_INVALID;
+  if (ctx->n && capacity > ctx->cap) return fail(ctx, PBF_ERR_STATE, "pbf_reserve must precede pbf_upload");
+  ctx->reserve = capacity;
+  return PBF_OK;
+}
+size_t pbf_slab_record_bytes(const pbf_ctx *ctx, int kind) {
+  if (!ctx) return 0;
+  switch (kind) {
+    case PBF_REC_MIGRANT: return ctx->fp64 ? sizeof(MigrantRec<double>) : sizeof(MigrantRec<float>);
+    case PBF_REC_GHOST: return ctx->fp64 ? sizeof(GhostRec<double>) : sizeof(GhostRec<float>);
+    case PBF_REC_FIELD: return ctx->fp64 ? sizeof(double4) : sizeof(float4);
+    default: return 0;
+  }
+}
+int pbf_slab_migrate(pbf_ctx *ctx, const pbf_slab_cut *cut, void *send_left, void *send_right, uint32_t cap_records,
+                     uint32_t counts[2]) {
+  if (int rc = slab_check(ctx)) return rc;
+  if (!cut || !counts) return fail(ctx, PBF_ERR_INVALID, "NULL argument");
+  return DISPATCH(ctx, slab_migrate, ctx, cut, send_left, send_right, cap_records, counts);
+}
+int pbf_slab_add_migrants(pbf_ctx *ctx, const void *recv_left, uint32_t n_left, const void *recv_right, uint32_t n_right) {
+  if (int rc = slab_check(ctx)) return rc;
+  return DISPATCH(ctx, slab_add_migrants, ctx, recv_left, n_left, recv_right, n_right);
+}
+int pbf_slab_ghosts(pbf_ctx *ctx, const pbf_slab_cut *cut, void *send_left, void *send_right, uint32_t cap_records,
+                    uint32_t counts[2]) {
+  if (int rc = slab_check(ctx)) return rc;
+  if (!cut || !counts) return fail(ctx, PBF_ERR_INVALID, "NULL argument");
+  return DISPATCH(ctx, slab_ghosts, ctx, cut, send_left, send_right, cap_records, counts);
+}
+int pbf_slab_add_ghosts(pbf_ctx *ctx, const void *recv_left, uint32_t n_left, const void *recv_right, uint32_t n_right) {
+  if (int rc = slab_check(ctx)) return rc;
+  return DISPATCH(ctx, slab_add_ghosts, ctx, recv_left, n_left, recv_right, n_right);
+}
+int pbf_slab_pack(pbf_ctx *ctx, void *send_left, void *send_right) {
+  if (int rc = slab_check(ctx)) return rc;
+  if (!ctx->sorted) return fail(ctx, PBF_ERR_STATE, "pbf_slab_pack needs pbf_stage_sort first");
+  return DISPATCH(ctx, slab_pack, ctx, send_left, send_right);
+}
+int pbf_slab_unpack(pbf_ctx *ctx, const void *recv_left, const void *recv_right) {
+  if (int rc = slab_check(ctx)) return rc;
+  if (!ctx->sorted) return fail(ctx, PBF_ERR_STATE, "pbf_slab_unpack needs pbf_stage_sort first");
+  return DISPATCH(ctx, slab_unpack, ctx, recv_left, recv_right);
+}
+int pbf_slab_finish(pbf_ctx *ctx) {
+  if (int rc = slab_check(ctx)) return rc;
+  return DISPATCH(ctx, slab_finish, ctx);
+}
+size_t pbf_owned_count(const pbf_ctx *ctx) { return ctx ? (ctx->slabActive ? ctx->nOwned : ctx->n) : 0; }
 
 }  // extern "C"

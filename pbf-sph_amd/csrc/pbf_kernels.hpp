@@ -31,7 +31,7 @@ __global__ __launch_bounds__(BLOCK) void k_predict(StepConsts<N> c, const vec4<N
   const vec4<N> p = pos4[i];
   vec4<N> v = vel4[i];
   N px, py, pz;
-  if (c.hasObstacles && type[i] == 1) {
+  if (c.hasObstacles && (type[i] & 1)) {
     px = p.x / c.scale, py = p.y / c.scale, pz = p.z / c.scale;
   } else {
     const N mass = p.w;
@@ -181,7 +181,7 @@ template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_rank_move(uint32_t n, uint32_t tableN,
                                                      const uint32_t *__restrict__ permTmp,
                                                      const uint32_t *__restrict__ table, ParticleArrays<N> src,
-                                                     ParticleArrays<N> dst) {
+                                                     ParticleArrays<N> dst, uint32_t *__restrict__ slotOf) {
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint32_t s = permTmp[i];
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(BLOCK) void k_rank_move(uint32_t n, uint32_t tableN
   dst.id[d] = src.id[s];
   dst.type[d] = src.type[s];
   dst.key[d] = k;
+  if (slotOf) slotOf[s] = d;  // slab mode: where did pre-sort particle s go
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -340,7 +341,7 @@ template <typename N> struct DiffuseOp {
     ca = a.colIn[i];
     mx = my = mz = mw = N(0);
     nn = 0;
-    if (c.hasObstacles && a.type[i] == 1) {
+    if (c.hasObstacles && a.type[i] != 0) {  // obstacle, or a ghost copy owned by the neighbouring slab
       a.colOut[i] = ca;
       return false;
     }
@@ -382,8 +383,8 @@ template <typename N, bool FAST> struct LambdaOp {
   vec4<N> pa;
   N mass, gx, gy, gz, rho;
   __device__ bool begin(const StepConsts<N> &c, const Args &a, uint32_t i) {
-    if (c.hasObstacles && a.type[i] == 1) {
-      a.pstar[i].w = N(0);
+    if (c.hasObstacles && a.type[i] != 0) {
+      if (a.type[i] & 1) a.pstar[i].w = N(0);  // obstacle: lambda = 0 (ompsph.hpp:218-221); a ghost keeps its owner's
       return false;
     }
     pa = a.pstar[i];
@@ -438,7 +439,7 @@ template <typename N, bool FAST> struct DeltaOp {
   __device__ bool begin(const StepConsts<N> &c, const Args &a, uint32_t i) {
     pa = a.pstarIn[i];
     ax = ay = az = N(0);
-    if (c.hasObstacles && a.type[i] == 1) {
+    if (c.hasObstacles && a.type[i] != 0) {
       a.pstarOut[i] = pa;
       return false;
     }
@@ -488,7 +489,7 @@ __device__ inline void gather_one_global(const StepConsts<N> &c, const typename 
   const typename Op::Src *src = Op::src(args);
   if (Op::kNeedsCandidateType && c.hasObstacles) {
     for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) {
-      if (args.type[b] != 1) op.add(c, src[b]);
+      if (!(args.type[b] & 1)) op.add(c, src[b]);
     });
   } else if (Op::kFilter) {  // lambda / delta: the branchy pair terms skip whole waves, keep one per trip
     for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { op.add(c, src[b]); });
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(BLOCK) void k_finalise(StepConsts<N> c, const uint8
                                                     vec4<N> *__restrict__ vel4) {
   const uint32_t a = blockIdx.x * BLOCK + threadIdx.x;
   if (a >= c.n) return;
-  if (c.hasObstacles && type[a] == 1) return;
+  if (c.hasObstacles && type[a] != 0) return;  // obstacles and ghosts do not move here
   const vec4<N> ps = pstar[a];
   vec4<N> p = pos4[a];
   vec4<N> v = vel4[a];

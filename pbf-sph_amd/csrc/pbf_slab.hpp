@@ -1,0 +1,213 @@
+// pbf_slab.hpp — device side of the multi-GPU slab decomposition (no reference counterpart: the
+// reference is single-device).  The domain is cut into slabs of whole cell columns
+// along x; every rank keeps the GLOBAL Morton keys and a table of the global size, so all the
+// single-GPU kernels run unchanged.  What is added here:
+//   * a deterministic 3-pass "select" (count / scan / emit) that, in array order,
+//       mode MIGRATE: compacts the particles that stay, and packs those whose cell column left
+//                     the slab into wire records for the left / right neighbour (ghosts of the
+//                     previous step are dropped on the way);
+//       mode GHOST:   packs a copy of the particles in the slab's first / last column for the
+//                     neighbour and remembers which particle each copy came from;
+//   * append kernels for what arrives, a histogram kernel for the re-assembled set,
+//   * field pack / unpack: after every lambda and delta launch the owners refresh their copies'
+//     {pStar, lambda} on the neighbour, addressed through the sort's source->slot map.
+// Ghost copies carry type bit 1 (TYPE_GHOST): they are candidates but never updated locally.
+#pragma once
+
+#include "pbf_kernels.hpp"
+
+namespace pbf {
+
+constexpr uint8_t TYPE_GHOST = 2;
+constexpr int SEL_ITEMS = 4;
+constexpr int SEL_TILE = BLOCK * SEL_ITEMS;
+
+template <typename N> struct MigrantRec {
+  vec4<N> pos4, vel4, col4, pstar;
+  uint64_t id;
+  uint32_t key, type;
+};
+template <typename N> struct GhostRec {
+  vec4<N> pstar, col4;
+  uint32_t key, type, pad0, pad1;
+};
+
+struct SlabCut {
+  uint32_t xlo, xhi;  // owned cell columns [xlo, xhi)
+  uint32_t hasLeft, hasRight;
+};
+
+enum { SEL_MIGRATE = 0, SEL_GHOST = 1 };
+// class ids: MIGRATE: 0 keep, 1 to-left, 2 to-right.  GHOST: 0 copy-for-left, 1 copy-for-right.
+template <int MODE> __device__ inline uint32_t slab_classes(uint32_t key, uint8_t type, const SlabCut &s) {
+  const uint32_t cx = compact10(key);
+  if (MODE == SEL_MIGRATE) {
+    if (type & TYPE_GHOST) return 0u;  // last step's copies are dropped
+    if (s.hasLeft && cx < s.xlo) return 2u;
+    if (s.hasRight && cx >= s.xhi) return 4u;
+    return 1u;
+  } else {
+    uint32_t m = 0;
+    if (s.hasLeft && cx == s.xlo) m |= 1u;
+    if (s.hasRight && cx + 1u == s.xhi) m |= 2u;
+    return m;
+  }
+}
+
+// pass 1: per-block class counts -> counts[cls * nb + block]
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_sel_count(uint32_t n, SlabCut s, const uint32_t *__restrict__ key,
+                                                     const uint8_t *__restrict__ type, uint32_t nb,
+                                                     uint32_t *__restrict__ counts) {
+  uint32_t c0 = 0, c1 = 0, c2 = 0;
+  const uint32_t base = blockIdx.x * SEL_TILE + threadIdx.x * SEL_ITEMS;
+#pragma unroll
+  for (int j = 0; j < SEL_ITEMS; ++j) {
+    const uint32_t i = base + j;
+    if (i < n) {
+      const uint32_t m = slab_classes<MODE>(key[i], type[i], s);
+      c0 += m & 1u, c1 += (m >> 1) & 1u, c2 += (m >> 2) & 1u;
+    }
+  }
+  uint32_t t0, t1, t2;
+  block_excl_scan(c0, &t0);
+  block_excl_scan(c1, &t1);
+  block_excl_scan(c2, &t2);
+  if (threadIdx.x == 0) counts[blockIdx.x] = t0, counts[nb + blockIdx.x] = t1, counts[2 * nb + blockIdx.x] = t2;
+}
+
+// pass 2: exclusive scan per class over the blocks; totals[cls] = grand total
+__global__ __launch_bounds__(BLOCK) void k_sel_scan(uint32_t nb, uint32_t *__restrict__ counts,
+                                                    uint32_t *__restrict__ totals) {
+  for (int cls = 0; cls < 3; ++cls) {
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += BLOCK) {
+      const uint32_t i = base + threadIdx.x;
+      const uint32_t v = i < nb ? counts[cls * nb + i] : 0u;
+      uint32_t total;
+      const uint32_t ex = block_excl_scan(v, &total);
+      if (i < nb) counts[cls * nb + i] = carry + ex;
+      carry += total;
+    }
+    if (threadIdx.x == 0) totals[cls] = carry;
+  }
+}
+
+// pass 3: emit in array order
+template <typename N, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_sel_emit(uint32_t n, SlabCut s, ParticleArrays<N> src, ParticleArrays<N> dst,
+                                                    uint32_t nb, const uint32_t *__restrict__ bases, void *sendL,
+                                                    void *sendR, uint32_t capRecords, uint32_t *__restrict__ srcL,
+                                                    uint32_t *__restrict__ srcR) {
+  const uint32_t base = blockIdx.x * SEL_TILE + threadIdx.x * SEL_ITEMS;
+  uint32_t m[SEL_ITEMS];
+  uint32_t c0 = 0, c1 = 0, c2 = 0;
+#pragma unroll
+  for (int j = 0; j < SEL_ITEMS; ++j) {
+    const uint32_t i = base + j;
+    m[j] = i < n ? slab_classes<MODE>(src.key[i], src.type[i], s) : 0u;
+    c0 += m[j] & 1u, c1 += (m[j] >> 1) & 1u, c2 += (m[j] >> 2) & 1u;
+  }
+  uint32_t t;
+  uint32_t p0 = block_excl_scan(c0, &t) + bases[blockIdx.x];
+  uint32_t p1 = block_excl_scan(c1, &t) + bases[nb + blockIdx.x];
+  uint32_t p2 = block_excl_scan(c2, &t) + bases[2 * nb + blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < SEL_ITEMS; ++j) {
+    const uint32_t i = base + j;
+    if (MODE == SEL_MIGRATE) {
+      if (m[j] & 1u) {  // stays: stable compaction into the other array set
+        const uint32_t d = p0++;
+        dst.pos4[d] = src.pos4[i], dst.vel4[d] = src.vel4[i], dst.col4[d] = src.col4[i], dst.pstar[d] = src.pstar[i];
+        dst.id[d] = src.id[i], dst.type[d] = src.type[i], dst.key[d] = src.key[i];
+      } else if (m[j] & 6u) {
+        const bool left = (m[j] & 2u) != 0;
+        const uint32_t d = left ? p1++ : p2++;
+        if (d < capRecords) {
+          MigrantRec<N> r;
+          r.pos4 = src.pos4[i], r.vel4 = src.vel4[i], r.col4 = src.col4[i], r.pstar = src.pstar[i];
+          r.id = src.id[i], r.key = src.key[i], r.type = src.type[i];
+          static_cast<MigrantRec<N> *>(left ? sendL : sendR)[d] = r;
+        }
+      }
+    } else {
+      if (m[j] & 1u) {
+        const uint32_t d = p0++;
+        if (d < capRecords) {
+          GhostRec<N> r;
+          r.pstar = src.pstar[i], r.col4 = src.col4[i], r.key = src.key[i], r.type = src.type[i] | TYPE_GHOST;
+          r.pad0 = r.pad1 = 0;
+          static_cast<GhostRec<N> *>(sendL)[d] = r;
+          srcL[d] = i;
+        }
+      }
+      if (m[j] & 2u) {
+        const uint32_t d = p1++;
+        if (d < capRecords) {
+          GhostRec<N> r;
+          r.pstar = src.pstar[i], r.col4 = src.col4[i], r.key = src.key[i], r.type = src.type[i] | TYPE_GHOST;
+          r.pad0 = r.pad1 = 0;
+          static_cast<GhostRec<N> *>(sendR)[d] = r;
+          srcR[d] = i;
+        }
+      }
+    }
+  }
+}
+
+template <typename N>
+__global__ __launch_bounds__(BLOCK) void k_append_migrants(uint32_t at, const MigrantRec<N> *__restrict__ recvL,
+                                                           uint32_t nL, const MigrantRec<N> *__restrict__ recvR,
+                                                           uint32_t nR, ParticleArrays<N> dst) {
+  const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= nL + nR) return;
+  const MigrantRec<N> r = j < nL ? recvL[j] : recvR[j - nL];
+  const uint32_t d = at + j;
+  dst.pos4[d] = r.pos4, dst.vel4[d] = r.vel4, dst.col4[d] = r.col4, dst.pstar[d] = r.pstar;
+  dst.id[d] = r.id, dst.type[d] = uint8_t(r.type), dst.key[d] = r.key;
+}
+
+template <typename N>
+__global__ __launch_bounds__(BLOCK) void k_append_ghosts(uint32_t at, const GhostRec<N> *__restrict__ recvL,
+                                                         uint32_t nL, const GhostRec<N> *__restrict__ recvR,
+                                                         uint32_t nR, ParticleArrays<N> dst) {
+  const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= nL + nR) return;
+  const GhostRec<N> r = j < nL ? recvL[j] : recvR[j - nL];
+  const uint32_t d = at + j;
+  const vec4<N> zero = make_vec4<N>(N(0), N(0), N(0), N(0));
+  dst.pos4[d] = zero, dst.vel4[d] = zero, dst.col4[d] = r.col4, dst.pstar[d] = r.pstar;
+  dst.id[d] = ~uint64_t(0), dst.type[d] = uint8_t(r.type), dst.key[d] = r.key;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_count_keys(uint32_t n, uint32_t tableN, const uint32_t *__restrict__ key,
+                                                      uint32_t *__restrict__ count) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n) atomicAdd(&count[min(key[i], tableN)], 1u);
+}
+
+// owners -> copies: {pStar, lambda} of the particles listed in srcL / srcR, read at their sorted slot
+template <typename N>
+__global__ __launch_bounds__(BLOCK) void k_pack_field(uint32_t nL, uint32_t nR, const uint32_t *__restrict__ srcL,
+                                                      const uint32_t *__restrict__ srcR,
+                                                      const uint32_t *__restrict__ slotOf,
+                                                      const vec4<N> *__restrict__ pstar, vec4<N> *__restrict__ outL,
+                                                      vec4<N> *__restrict__ outR) {
+  const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j < nL) outL[j] = pstar[slotOf[srcL[j]]];
+  else if (j < nL + nR) outR[j - nL] = pstar[slotOf[srcR[j - nL]]];
+}
+
+// copies <- owners: the copies sit at pre-sort indices ghostAt + j in arrival order (left, then right)
+template <typename N>
+__global__ __launch_bounds__(BLOCK) void k_unpack_field(uint32_t ghostAt, uint32_t nL, uint32_t nR,
+                                                        const vec4<N> *__restrict__ inL,
+                                                        const vec4<N> *__restrict__ inR,
+                                                        const uint32_t *__restrict__ slotOf,
+                                                        vec4<N> *__restrict__ pstar) {
+  const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= nL + nR) return;
+  pstar[slotOf[ghostAt + j]] = j < nL ? inL[j] : inR[j - nL];
+}
+
+}  // namespace pbf

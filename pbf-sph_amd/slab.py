@@ -1,0 +1,236 @@
+"""Slab decomposition of the PBF-SPH step across GPUs: one process per GPU, RCCL over xGMI through
+torch.distributed (backend "nccl"); the same driver runs on CPU tensors with "gloo" for tests.
+
+The reference is single-device — this layer has no counterpart there; its
+correctness statement is "N ranks == 1 rank".  Layout: rank g owns the cell columns
+[cuts[g], cuts[g+1]) of the GLOBAL grid (every rank passes the same bounds) plus a one-cell layer of
+copies ("ghosts") of its x-neighbours' boundary columns.  Per step:
+
+    predict ─ migrate ⇄ add_migrants ─ ghosts ⇄ add_ghosts ─ sort ─ diffuse ─
+    K × { lambda ─ pack ⇄ unpack ─ delta ─ pack ⇄ unpack } ─ finalise ─ finish
+
+⇄ = neighbour exchange (point-to-point send/recv with the left and right rank, one batch per
+phase; messages are O(100 KB – few MB), so the cost is latency, not xGMI bandwidth).  All numerics
+stay in the engine (libpbf_hip.so through the C ABI); this file only sequences and moves bytes.
+"""
+import ctypes as C
+
+import numpy as np
+
+REC_MIGRANT, REC_GHOST, REC_FIELD = 0, 1, 2
+
+
+def column_of(x_world, scale=500.0, h=0.1, min_bound_x=0.0):
+    """Grid column of a world-space x (ompsph.hpp:132-135,152: (x/scale - minExtent)/h, padding 2h)."""
+    return int((x_world / scale - (min_bound_x / scale - 2 * h)) / h)
+
+
+def even_cuts(nranks, box_x, scale=500.0, h=0.1):
+    """Equal-width slabs over [0, box_x]; the first / last slab also take the padding columns."""
+    cols = [column_of(box_x * g / nranks, scale, h) for g in range(nranks + 1)]
+    cols[0], cols[-1] = 0, 1024
+    return cols
+
+
+def balanced_cuts(nranks, x_world_all, box_x, scale=500.0, h=0.1):
+    """Cuts at particle-count quantiles of the column histogram (call with the gathered x of all ranks)."""
+    col = ((np.asarray(x_world_all, np.float64) / scale + 2 * h) / h).astype(np.int64)
+    order = np.sort(col)
+    cuts = [0]
+    for g in range(1, nranks):
+        cuts.append(int(order[min(len(order) - 1, (len(order) * g) // nranks)]))
+    cuts.append(1024)
+    for g in range(1, nranks + 1):  # strictly increasing, at least one column each
+        cuts[g] = max(cuts[g], cuts[g - 1] + 1)
+    return cuts
+
+
+class HipEngine:
+    """The product engine: pbf_sph_amd.Solver (C ABI) + torch device buffers for the wire."""
+
+    def __init__(self, solver, torch, device):
+        self.s, self.torch, self.device = solver, torch, device
+        self.L, self.ctx = solver.L, solver.ctx
+        self.bytes = {k: self.L.pbf_slab_record_bytes(self.ctx, k) for k in (REC_MIGRANT, REC_GHOST, REC_FIELD)}
+
+    def alloc(self, nbytes):
+        return self.torch.empty(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def record_bytes(self, kind):
+        return self.bytes[kind]
+
+    def _cut(self, cut):
+        from . import capi
+        return capi.SlabCut(cut[0], cut[1], int(cut[2]), int(cut[3]))
+
+    def predict(self, p):
+        self.s.stage("predict", p)
+
+    def migrate(self, cut, send_l, send_r, cap):
+        c, out = self._cut(cut), (C.c_uint32 * 2)()
+        self.s._chk(self.L.pbf_slab_migrate(self.ctx, C.byref(c), self._p(send_l), self._p(send_r), cap, out),
+                    "pbf_slab_migrate")
+        return int(out[0]), int(out[1])
+
+    def add_migrants(self, recv_l, n_l, recv_r, n_r):
+        self.s._chk(self.L.pbf_slab_add_migrants(self.ctx, self._p(recv_l), n_l, self._p(recv_r), n_r),
+                    "pbf_slab_add_migrants")
+
+    def ghosts(self, cut, send_l, send_r, cap):
+        c, out = self._cut(cut), (C.c_uint32 * 2)()
+        self.s._chk(self.L.pbf_slab_ghosts(self.ctx, C.byref(c), self._p(send_l), self._p(send_r), cap, out),
+                    "pbf_slab_ghosts")
+        return int(out[0]), int(out[1])
+
+    def add_ghosts(self, recv_l, n_l, recv_r, n_r):
+        self.s._chk(self.L.pbf_slab_add_ghosts(self.ctx, self._p(recv_l), n_l, self._p(recv_r), n_r),
+                    "pbf_slab_add_ghosts")
+
+    def stage(self, name, p):
+        self.s.stage(name, p)
+
+    def pack(self, send_l, send_r):
+        self.s._chk(self.L.pbf_slab_pack(self.ctx, self._p(send_l), self._p(send_r)), "pbf_slab_pack")
+
+    def unpack(self, recv_l, recv_r):
+        self.s._chk(self.L.pbf_slab_unpack(self.ctx, self._p(recv_l), self._p(recv_r)), "pbf_slab_unpack")
+
+    def finish(self):
+        self.s._chk(self.L.pbf_slab_finish(self.ctx), "pbf_slab_finish")
+
+    def sync(self):
+        self.s.sync()
+
+    @property
+    def n_owned(self):
+        return self.L.pbf_owned_count(self.ctx)
+
+
+class SlabSolver:
+    """Sequences one rank's share of the step and the neighbour exchanges.
+
+    engine : HipEngine (GPU) — tests plug a CPU engine with the same methods
+    dist   : torch.distributed (initialised), or None for a single rank
+    cuts   : nranks + 1 column boundaries, identical on every rank
+    """
+
+    def __init__(self, engine, dist, rank, nranks, cuts, cap_records, stage_via_host=False):
+        # stage_via_host: bounce the wire buffers through CPU tensors (lets several ranks share ONE GPU
+        # under the "gloo" backend for tests; production uses "nccl" = RCCL straight from device memory)
+        self.e, self.dist, self.rank, self.nranks = engine, dist, rank, nranks
+        self.stage_via_host = stage_via_host
+        self.set_cuts(cuts)
+        self.cap = int(cap_records)
+        big = max(engine.record_bytes(REC_MIGRANT), engine.record_bytes(REC_GHOST))
+        self.send = [engine.alloc(self.cap * big) for _ in range(2)]
+        self.recv = [engine.alloc(self.cap * big) for _ in range(2)]
+        self.cnt_send = [engine.alloc(8) for _ in range(2)]
+        self.cnt_recv = [engine.alloc(8) for _ in range(2)]
+        self.sent = [0, 0]
+        self.got = [0, 0]
+        self.stats = dict(migrated=0, ghosts=0, exchanges=0)
+
+    def set_cuts(self, cuts):
+        assert len(cuts) == self.nranks + 1
+        self.cuts = list(cuts)
+        self.left = self.rank - 1 if self.rank > 0 else None
+        self.right = self.rank + 1 if self.rank + 1 < self.nranks else None
+        self.cut = (self.cuts[self.rank], self.cuts[self.rank + 1], self.left is not None, self.right is not None)
+
+    # -- neighbour exchange -----------------------------------------------------------------------
+    def _exchange(self, send_bytes, recv_bytes):
+        """One batched point-to-point round: send_bytes/recv_bytes = (left, right) byte counts."""
+        if self.dist is None or self.nranks == 1:
+            return
+        ops, back = [], []
+        for side, peer in ((0, self.left), (1, self.right)):
+            if peer is None:
+                continue
+            if recv_bytes[side]:
+                dst = self.recv[side][:recv_bytes[side]]
+                if self.stage_via_host:
+                    host = self.e.torch.empty(recv_bytes[side], dtype=self.e.torch.uint8)
+                    back.append((dst, host))
+                    dst = host
+                ops.append(self.dist.P2POp(self.dist.irecv, dst, peer))
+            if send_bytes[side]:
+                src = self.send[side][:send_bytes[side]]
+                if self.stage_via_host:
+                    self.e.sync()
+                    src = src.cpu()
+                ops.append(self.dist.P2POp(self.dist.isend, src, peer))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+            for dst, host in back:
+                dst.copy_(host)
+            self.stats["exchanges"] += 1
+
+    def _exchange_counts(self, n_l, n_r):
+        if self.dist is None or self.nranks == 1:
+            return 0, 0
+        t = self.e.torch
+        ops = []
+        for side, peer, n in ((0, self.left, n_l), (1, self.right, n_r)):
+            if peer is None:
+                continue
+            if self.stage_via_host:
+                self.cnt_send[side] = t.tensor([n], dtype=t.int64)
+                self.cnt_recv[side] = t.zeros(1, dtype=t.int64)
+                ops.append(self.dist.P2POp(self.dist.irecv, self.cnt_recv[side], peer))
+                ops.append(self.dist.P2POp(self.dist.isend, self.cnt_send[side], peer))
+            else:
+                self.cnt_send[side][:8].copy_(t.tensor([n], dtype=t.int64).view(t.uint8))
+                ops.append(self.dist.P2POp(self.dist.irecv, self.cnt_recv[side][:8], peer))
+                ops.append(self.dist.P2POp(self.dist.isend, self.cnt_send[side][:8], peer))
+        for w in self.dist.batch_isend_irecv(ops):
+            w.wait()
+        out = [0, 0]
+        for side, peer in ((0, self.left), (1, self.right)):
+            if peer is not None:
+                c = self.cnt_recv[side] if self.stage_via_host else self.cnt_recv[side][:8].view(t.int64).cpu()
+                out[side] = int(c[0])
+        return out[0], out[1]
+
+    def _swap(self, kind, n_l, n_r):
+        """Tell the neighbours how many records come, then move them. Returns (from_left, from_right)."""
+        g_l, g_r = self._exchange_counts(n_l, n_r)
+        if max(g_l, g_r) > self.cap:
+            raise RuntimeError(f"slab wire buffer too small: {max(g_l, g_r)} records > cap {self.cap}")
+        b = self.e.record_bytes(kind)
+        self._exchange((n_l * b, n_r * b), (g_l * b, g_r * b))
+        return g_l, g_r
+
+    # -- one step ---------------------------------------------------------------------------------
+    def step(self, p):
+        e = self.e
+        e.predict(p)
+        n_l, n_r = e.migrate(self.cut, self.send[0], self.send[1], self.cap)
+        g_l, g_r = self._swap(REC_MIGRANT, n_l, n_r)
+        e.add_migrants(self.recv[0], g_l, self.recv[1], g_r)
+        self.stats["migrated"] += n_l + n_r
+        n_l, n_r = e.ghosts(self.cut, self.send[0], self.send[1], self.cap)
+        self.sent = [n_l, n_r]
+        g_l, g_r = self._swap(REC_GHOST, n_l, n_r)
+        self.got = [g_l, g_r]
+        e.add_ghosts(self.recv[0], g_l, self.recv[1], g_r)
+        self.stats["ghosts"] = g_l + g_r
+        e.stage("sort", p)
+        e.stage("diffuse", p)
+        fb = e.record_bytes(REC_FIELD)
+        for _ in range(int(p.iteration)):
+            for name in ("lambda", "delta"):
+                e.stage(name, p)
+                e.pack(self.send[0], self.send[1])
+                self._exchange((self.sent[0] * fb, self.sent[1] * fb), (self.got[0] * fb, self.got[1] * fb))
+                e.unpack(self.recv[0], self.recv[1])
+        e.stage("finalise", p)
+        e.finish()
+
+    def steps(self, p, count):
+        for _ in range(count):
+            self.step(p)

@@ -91,6 +91,7 @@ def lib():
         L.pbf_oracle_scene_dambreak.argtypes = [C.c_int, C.c_size_t] + [C.c_void_p] * 5 + [C.POINTER(C.c_double)]
         L.pbf_oracle_motion_offset.argtypes = [C.c_int, C.c_uint64, C.c_void_p]
         L.pbf_oracle_set_pow4.argtypes = [C.c_void_p, C.c_int]
+        L.pbf_oracle_set_scratch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -236,6 +237,12 @@ class Oracle:
         a = np.empty(self.n, self.dtype)
         self.L.pbf_oracle_get_lambda(self.h, _vp(a))
         return a
+
+    def set_scratch(self, keys=None, pstar=None, lambdas=None):
+        k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        ps = None if pstar is None else np.ascontiguousarray(pstar, self.dtype)
+        la = None if lambdas is None else np.ascontiguousarray(lambdas, self.dtype)
+        self.L.pbf_oracle_set_scratch(self.h, _vp(k), _vp(ps), _vp(la))
 
     def table(self):
         t = np.empty(self.L.pbf_oracle_table_size(self.h), np.uint64)

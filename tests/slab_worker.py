@@ -1,0 +1,72 @@
+"""Worker of the slab tests: one rank of an N-rank run of pbf-sph_amd/slab.py.
+
+  engine "oracle": CPU engine (tests/slab_engines.py), gloo, CPU tensors        — runs anywhere
+  engine "hip"   : the product engine on cuda:0, gloo with host-staged buffers   — several ranks share ONE GPU
+Writes the rank's final owned particles to <out>/rank<r>.npz."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from conftest import load_package  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--engine", default="oracle")
+    ap.add_argument("--scene", default="cubes2048")
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--iteration", type=int, default=4)
+    ap.add_argument("--cuts", default="even")
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_package()
+    from pbf_sph_amd import slab
+
+    if a.scene.startswith("cubes"):
+        sc, side = pkg.scene_cubes(int(a.scene[5:])), 1000.0
+    else:
+        sc, side = pkg.scene_dambreak(int(a.scene[3:]))
+    p = pkg.default_params(a.iteration, side)
+    if a.cuts == "even":
+        cuts = slab.even_cuts(world, side)
+    elif a.cuts.startswith("x:"):  # explicit world-space cut positions
+        cuts = [0] + [slab.column_of(float(v)) for v in a.cuts[2:].split(",")] + [1024]
+    else:
+        cuts = slab.balanced_cuts(world, sc["pos"][:, 0], side)
+    col = ((sc["pos"][:, 0].astype(np.float64) / 500.0 + 0.2) / 0.1).astype(np.int64)
+    mine = (col >= cuts[rank]) & (col < cuts[rank + 1])
+    part = {k: v[mine] for k, v in sc.items()}
+    cap = len(sc["id"])
+    if a.engine == "oracle":
+        from slab_engines import OracleEngine
+        eng = OracleEngine(False, device_pow=True)
+        eng.upload(**part)
+        get = eng.download
+        stage = False
+    else:
+        s = pkg.Solver(h=0.1, device=0)
+        s._chk(s.L.pbf_reserve(s.ctx, cap), "pbf_reserve")
+        s.upload(**part)
+        eng = slab.HipEngine(s, torch, torch.device("cuda", 0))
+        get = s.download
+        stage = True
+    drv = slab.SlabSolver(eng, dist, rank, world, cuts, cap, stage_via_host=stage)
+    drv.steps(p, a.steps)
+    out = get()
+    os.makedirs(a.out, exist_ok=True)
+    np.savez(os.path.join(a.out, f"rank{rank}.npz"), migrated=drv.stats["migrated"], ghosts=drv.stats["ghosts"],
+             exchanges=drv.stats["exchanges"], cuts=np.array(cuts), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
