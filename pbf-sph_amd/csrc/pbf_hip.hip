@@ -69,6 +69,9 @@ struct pbf_ctx {
   bool slabActive = false, realObstacles = false;
   size_t reserve = 0;        // pbf_reserve: capacity kept for migrants and ghost copies
   uint32_t nOwned = 0, sentL = 0, sentR = 0, gotL = 0, gotR = 0;
+  DevBuf nbrList, nbrCount;  // neighbour lists handed from the lambda launch to the delta launch (NBR_CAP per particle)
+  bool nbrValid = false;     // the lists describe pstar[pcur] as it is now
+  bool reuseLists = true;    // option "reuse_lists"
   DevBuf bricks, brickCtl;  // non-empty brick list; brickCtl = {nActive, ticket[kTickets]}
   uint32_t gatherSeq = 0;   // which ticket word the next persistent gather launch uses
   int numCUs = 256;
@@ -138,6 +141,8 @@ int ensure_particles(pbf_ctx *ctx, size_t n) {
     if (int rc = ensure(ctx, ctx->pstar[s], n * v)) return rc;
   if (int rc = ensure(ctx, ctx->permTmp, n * 4)) return rc;
   if (int rc = ensure(ctx, ctx->slotOf, n * 4)) return rc;
+  if (int rc = ensure(ctx, ctx->nbrCount, n * 4)) return rc;
+  if (int rc = ensure(ctx, ctx->nbrList, ((n + BLOCK - 1) / BLOCK) * size_t(NBR_CAP) * BLOCK * 4)) return rc;
   ctx->cap = n;
   return PBF_OK;
 }
@@ -313,6 +318,7 @@ template <typename N> int stage_predict(pbf_ctx *ctx, const pbf_params *p) {
   LAUNCH_CHECK(ctx);
   ctx->pcur = s;
   ctx->sorted = false;
+  ctx->nbrValid = false;
   ctx->counted = true;
   ctx->countedTableN = c.tableN;
   return PBF_OK;
@@ -349,6 +355,7 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
   ctx->cur = d;
   ctx->pcur = d;
   ctx->sorted = true;
+  ctx->nbrValid = false;
   ctx->counted = false;
   return PBF_OK;
 }
@@ -358,7 +365,10 @@ inline int other_pstar(const pbf_ctx *ctx) { return ctx->pcur == 2 ? ctx->cur : 
 
 // Launch one gather stage.  gatherKind picks the kernel (option "gather" / env PBF_GATHER);
 // PBF_FLAG_NO_LDS always forces the plain per-particle global walk.
-template <typename N, typename Op> int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args) {
+enum GatherMode { GATHER_PLAIN = 0, GATHER_SAVE_LISTS = 1, GATHER_FROM_LISTS = 2 };
+
+template <typename N, typename Op>
+int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, GatherMode mode = GATHER_PLAIN) {
   const uint32_t *key = ctx->key[ctx->cur].as<const uint32_t>();
   const uint32_t *table = ctx->table.as<const uint32_t>();
   if ((ctx->desc.flags & PBF_FLAG_NO_LDS) || ctx->gatherKind == 0) {
@@ -370,12 +380,19 @@ template <typename N, typename Op> int launch_gather(pbf_ctx *ctx, const StepCon
     return PBF_OK;
   }
   if (ctx->gatherKind == 1) {
-    switch (ctx->listMax ? ctx->listMax : 16u) {
-      case 12: hipLaunchKernelGGL((k_gather_lists<N, Op, 12>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
-      case 24: hipLaunchKernelGGL((k_gather_lists<N, Op, 24>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
-      case 48: hipLaunchKernelGGL((k_gather_lists<N, Op, 48>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
-      case 32: hipLaunchKernelGGL((k_gather_lists<N, Op, 32>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
-      default: hipLaunchKernelGGL((k_gather_lists<N, Op, 16>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table); break;
+    uint32_t *nl = ctx->nbrList.as<uint32_t>(), *nc = ctx->nbrCount.as<uint32_t>();
+    const dim3 g = grid_for(ctx->n), b(BLOCK);
+    if (mode == GATHER_FROM_LISTS) {
+      hipLaunchKernelGGL((k_gather_from_lists<N, Op>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
+    } else if (mode == GATHER_SAVE_LISTS) {
+      hipLaunchKernelGGL((k_gather_lists<N, Op, 16, true>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
+    } else {
+      switch (ctx->listMax ? ctx->listMax : 16u) {
+        case 12: hipLaunchKernelGGL((k_gather_lists<N, Op, 12>), g, b, 0, ctx->stream, c, args, key, table, nl, nc); break;
+        case 24: hipLaunchKernelGGL((k_gather_lists<N, Op, 24>), g, b, 0, ctx->stream, c, args, key, table, nl, nc); break;
+        case 32: hipLaunchKernelGGL((k_gather_lists<N, Op, 32>), g, b, 0, ctx->stream, c, args, key, table, nl, nc); break;
+        default: hipLaunchKernelGGL((k_gather_lists<N, Op, 16>), g, b, 0, ctx->stream, c, args, key, table, nl, nc); break;
+      }
     }
     LAUNCH_CHECK(ctx);
     return PBF_OK;
@@ -427,14 +444,18 @@ template <typename N> int stage_lambda(pbf_ctx *ctx, const pbf_params *p) {
   if (int rc = make_consts<N>(ctx, p, c)) return rc;
   StageTimer t(ctx, ST_LAMBDA);
   const int s = ctx->cur;
+  // the survivors of lambda's filter are exactly delta's (same pStar): hand them over through HBM
+  const bool lists = ctx->gatherKind == 1 && ctx->reuseLists && !(ctx->desc.flags & PBF_FLAG_NO_LDS);
+  const GatherMode save = lists ? GATHER_SAVE_LISTS : GATHER_PLAIN;
+  ctx->nbrValid = lists;
   if (ctx->fast) {
     typename LambdaOp<N, true>::Args args{ctx->pstar[ctx->pcur].as<vec4<N>>(), ctx->pos4[s].as<const vec4<N>>(),
                                           ctx->type[s].as<const uint8_t>()};
-    return launch_gather<N, LambdaOp<N, true>>(ctx, c, args);
+    return launch_gather<N, LambdaOp<N, true>>(ctx, c, args, save);
   }
   typename LambdaOp<N, false>::Args args{ctx->pstar[ctx->pcur].as<vec4<N>>(), ctx->pos4[s].as<const vec4<N>>(),
                                          ctx->type[s].as<const uint8_t>()};
-  return launch_gather<N, LambdaOp<N, false>>(ctx, c, args);
+  return launch_gather<N, LambdaOp<N, false>>(ctx, c, args, save);
 }
 
 template <typename N> int stage_delta(pbf_ctx *ctx, const pbf_params *p) {
@@ -442,15 +463,17 @@ template <typename N> int stage_delta(pbf_ctx *ctx, const pbf_params *p) {
   if (int rc = make_consts<N>(ctx, p, c)) return rc;
   StageTimer t(ctx, ST_DELTA);
   const int s = ctx->cur, in = ctx->pcur, out = other_pstar(ctx);
+  const GatherMode from = ctx->nbrValid ? GATHER_FROM_LISTS : GATHER_PLAIN;
+  ctx->nbrValid = false;  // delta moves pStar: the lists are stale afterwards
   int rc;
   if (ctx->fast) {
     typename DeltaOp<N, true>::Args args{ctx->pstar[in].as<const vec4<N>>(), ctx->pstar[out].as<vec4<N>>(),
                                          ctx->type[s].as<const uint8_t>()};
-    rc = launch_gather<N, DeltaOp<N, true>>(ctx, c, args);
+    rc = launch_gather<N, DeltaOp<N, true>>(ctx, c, args, from);
   } else {
     typename DeltaOp<N, false>::Args args{ctx->pstar[in].as<const vec4<N>>(), ctx->pstar[out].as<vec4<N>>(),
                                           ctx->type[s].as<const uint8_t>()};
-    rc = launch_gather<N, DeltaOp<N, false>>(ctx, c, args);
+    rc = launch_gather<N, DeltaOp<N, false>>(ctx, c, args, from);
   }
   if (rc) return rc;
   ctx->pcur = out;
@@ -563,6 +586,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   if (n == "list_max") ctx->listMax = uint32_t(value);
   else if (n == "gather") ctx->gatherKind = int(value);
   else if (n == "tile_cap") ctx->tileCap = uint32_t(value);
+  else if (n == "reuse_lists") ctx->reuseLists = value != 0;
   else if (n == "pad_lds") ctx->padLds = uint32_t(value);
   else return fail(ctx, PBF_ERR_INVALID, "unknown option " + n);
   return PBF_OK;
@@ -643,7 +667,7 @@ void pbf_destroy(pbf_ctx *ctx) {
                    &ctx->id[0],   &ctx->id[1],   &ctx->type[0], &ctx->type[1], &ctx->key[0],   &ctx->key[1],
                    &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2], &ctx->count, &ctx->table,   &ctx->blockSums,
                    &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl,
-                   &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR};
+                   &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR};
   for (DevBuf *b : all)
     if (b->p) (void)hipFree(b->p);
   if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);

@@ -777,10 +777,19 @@ __device__ inline uint32_t neighbour_code(uint32_t xm, uint32_t ym, uint32_t zm,
   return x | y | z;
 }
 
-template <typename N, typename Op, int LMAX>
+// Neighbour lists kept in HBM between the lambda and the delta launch of ONE solver iteration: both
+// see the same pStar, hence the same filtered candidates in the same order, so delta can skip the
+// 27-cell walk and the filter altogether.  Layout [block][slot][thread] (coalesced 1 KiB rows), at
+// most NBR_CAP slots per particle; a particle with more survivors is marked NBR_OVERFLOW and walks.
+constexpr uint32_t NBR_CAP = 64;
+constexpr uint32_t NBR_OVERFLOW = 0xFFFFFFFFu;
+
+template <typename N, typename Op, int LMAX, bool SAVE = false>
 __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typename Op::Args args,
                                                         const uint32_t *__restrict__ key,
-                                                        const uint32_t *__restrict__ table) {
+                                                        const uint32_t *__restrict__ table,
+                                                        uint32_t *__restrict__ nbrList,
+                                                        uint32_t *__restrict__ nbrCount) {
   __shared__ uint32_t list[(Op::kFilter ? LMAX : 1) * BLOCK];
   const uint32_t tid = threadIdx.x;
   const uint32_t i = blockIdx.x * BLOCK + tid;
@@ -790,24 +799,57 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
     return;
   }
   Op op;
+  if (!op.begin(c, args, i)) {
+    if (SAVE) nbrCount[i] = 0;
+    return;
+  }
+  const typename Op::Src *src = Op::src(args);
+  uint32_t nl = 0, written = 0;
+  uint32_t *mine = SAVE ? nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK + tid : nullptr;
+  auto drain = [&]() {
+#pragma unroll 2
+    for (uint32_t q = 0; q < nl; ++q) {
+      const uint32_t b = list[q * BLOCK + tid];
+      if (SAVE && written + q < NBR_CAP) mine[(written + q) * BLOCK] = b;
+      op.add_bf(c, src[b]);
+    }
+    written += nl;
+    nl = 0;
+  };
+  // same walk as kernel A (lanes of one cell stay in lockstep => their candidate loads coalesce);
+  // phase A only filters, phase B (drain) runs the exact pair terms for the survivors, in order
+  for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) {
+    const bool hit = op.near(c, src[b]);
+    list[nl * BLOCK + tid] = b;  // branch-free append: the slot is kept only on a hit
+    nl += hit ? 1u : 0u;
+    if (__any(nl == uint32_t(LMAX))) drain();  // every lane active here drains together
+  });
+  drain();
+  if (SAVE) nbrCount[i] = written <= NBR_CAP ? written : NBR_OVERFLOW;
+  op.end(c, args, i);
+}
+
+// List-driven gather: the survivors recorded by the previous k_gather_lists<.., SAVE> launch on the
+// same pStar, visited in the recorded (= reference) order; NBR_OVERFLOW particles walk their 27 cells.
+template <typename N, typename Op>
+__global__ __launch_bounds__(BLOCK) void k_gather_from_lists(StepConsts<N> c, typename Op::Args args,
+                                                             const uint32_t *__restrict__ key,
+                                                             const uint32_t *__restrict__ table,
+                                                             const uint32_t *__restrict__ nbrList,
+                                                             const uint32_t *__restrict__ nbrCount) {
+  const uint32_t tid = threadIdx.x;
+  const uint32_t i = blockIdx.x * BLOCK + tid;
+  if (i >= c.n) return;
+  Op op;
   if (!op.begin(c, args, i)) return;
   const typename Op::Src *src = Op::src(args);
-  {
-    uint32_t nl = 0;
-    auto drain = [&]() {
+  const uint32_t cnt = nbrCount[i];
+  if (cnt == NBR_OVERFLOW) {
+    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { op.add(c, src[b]); });
+  } else {
+    const uint32_t *mine = nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK + tid;
 #pragma unroll 2
-      for (uint32_t q = 0; q < nl; ++q) op.add_bf(c, src[list[q * BLOCK + tid]]);
-      nl = 0;
-    };
-    // same walk as kernel A (lanes of one cell stay in lockstep => their candidate loads coalesce);
-    // phase A only filters, phase B (drain) runs the exact pair terms for the survivors, in order
-    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) {
-      const bool hit = op.near(c, src[b]);
-      list[nl * BLOCK + tid] = b;  // branch-free append: the slot is kept only on a hit
-      nl += hit ? 1u : 0u;
-      if (__any(nl == uint32_t(LMAX))) drain();  // every lane active here drains together
-    });
-    drain();
+    for (uint32_t q = 0; q < cnt; ++q) op.add_bf(c, src[mine[q * BLOCK]]);
   }
   op.end(c, args, i);
 }

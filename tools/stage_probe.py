@@ -32,6 +32,7 @@ for fast in (0, 1):
             s.set_option("list_max", int(rest[0]))
         s.upload(**st)
         s.stage("predict", p).stage("sort", p)
+        s.set_option("diag", int(probe))
         for _ in range(3):
             s.stage(args.stage, p)
         s.sync()
