@@ -387,7 +387,7 @@ template <typename N> struct Oracle final : pbf_oracle {
     std::vector<V3<N>> vnew = v;
     if (c.vorticity) {
       foreach_1d(c.threads, cnt, [&](size_t a) {
-        if (type[a] == 1) return;
+        if (type[a] != 0) return;
         V3<N> w{N(0), N(0), N(0)};
         foreach_grid(zIndex[a], [&](size_t b) {
           const N r = distance(pStar[a], pStar[b]);
@@ -398,7 +398,7 @@ template <typename N> struct Oracle final : pbf_oracle {
         omega[a] = w;
       });
       foreach_1d(c.threads, cnt, [&](size_t a) {
-        if (type[a] == 1) return;
+        if (type[a] != 0) return;
         V3<N> eta{N(0), N(0), N(0)};
         foreach_grid(zIndex[a], [&](size_t b) {
           const N r = distance(pStar[a], pStar[b]);
@@ -417,7 +417,7 @@ template <typename N> struct Oracle final : pbf_oracle {
     if (c.xsph) {
       std::vector<V3<N>> base = vnew;
       foreach_1d(c.threads, cnt, [&](size_t a) {
-        if (type[a] == 1) return;
+        if (type[a] != 0) return;
         V3<N> acc{N(0), N(0), N(0)};
         foreach_grid(zIndex[a], [&](size_t b) {
           const N r = distance(pStar[a], pStar[b]);

@@ -397,6 +397,11 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
     LAUNCH_CHECK(ctx);
     return PBF_OK;
   }
+  if constexpr (!Op::kTileable) {
+    hipLaunchKernelGGL((k_gather_global<N, Op>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table);
+    LAUNCH_CHECK(ctx);
+    return PBF_OK;
+  } else {
   constexpr int BZ = kBrickZ, THREADS = 256;
   using B = Brick2<BZ>;
   using Src = typename Op::Src;
@@ -425,6 +430,7 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
   ctx->gatherSeq++;
   LAUNCH_CHECK(ctx);
   return PBF_OK;
+  }
 }
 
 template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p) {
@@ -480,6 +486,31 @@ template <typename N> int stage_delta(pbf_ctx *ctx, const pbf_params *p) {
   return PBF_OK;
 }
 
+// Opt-in extras (pbf_params.vorticity / .xsph), absent from the reference: see VorticityOp / XsphOp.
+template <typename N, bool FAST> int extras_impl(pbf_ctx *ctx, const pbf_params *p, const StepConsts<N> &c) {
+  const int s = ctx->cur, o = 1 - s;
+  const uint8_t *type = ctx->type[s].as<const uint8_t>();
+  const vec4<N> *ps = ctx->pstar[s].as<const vec4<N>>();
+  if (p->vorticity) {
+    vec4<N> *omega = ctx->pstar[2].as<vec4<N>>();
+    typename VorticityOp<N, FAST>::Args a1{ps, ctx->vel4[s].as<const vec4<N>>(), omega, type};
+    if (int rc = launch_gather<N, VorticityOp<N, FAST>>(ctx, c, a1)) return rc;
+    typename VorticityForceOp<N, FAST>::Args a2{ps, omega, ctx->vel4[s].as<const vec4<N>>(), ctx->vel4[o].as<vec4<N>>(), type};
+    if (int rc = launch_gather<N, VorticityForceOp<N, FAST>>(ctx, c, a2)) return rc;
+    std::swap(ctx->vel4[s], ctx->vel4[o]);
+  }
+  if (p->xsph) {
+    typename XsphOp<N, FAST>::Args a3{ps, ctx->vel4[s].as<const vec4<N>>(), ctx->vel4[o].as<vec4<N>>(), type};
+    if (int rc = launch_gather<N, XsphOp<N, FAST>>(ctx, c, a3)) return rc;
+    std::swap(ctx->vel4[s], ctx->vel4[o]);
+  }
+  return PBF_OK;
+}
+template <typename N> int extras(pbf_ctx *ctx, const pbf_params *p, const StepConsts<N> &c) {
+  if (ctx->slabActive) return fail(ctx, PBF_ERR_INVALID, "vorticity / xsph are not available in slab mode yet");
+  return ctx->fast ? extras_impl<N, true>(ctx, p, c) : extras_impl<N, false>(ctx, p, c);
+}
+
 template <typename N> int stage_finalise(pbf_ctx *ctx, const pbf_params *p) {
   StepConsts<N> c;
   if (int rc = make_consts<N>(ctx, p, c)) return rc;
@@ -494,6 +525,8 @@ template <typename N> int stage_finalise(pbf_ctx *ctx, const pbf_params *p) {
     std::swap(ctx->pstar[ctx->pcur], ctx->pstar[s]);
     ctx->pcur = s;
   }
+  ctx->nbrValid = false;
+  if (p->vorticity || p->xsph) return extras<N>(ctx, p, c);
   return PBF_OK;
 }
 

@@ -332,8 +332,10 @@ template <typename N> struct DiffuseOp {
   };
   static constexpr bool kNeedsCandidateType = true;  // obstacles are skipped as candidates (ompsph.hpp:194)
   static constexpr bool kFilter = false;             // no distance test in diffuse: every candidate counts
+  static constexpr bool kTileable = true;            // has a single source array the brick kernel can stage
   __device__ bool near(const StepConsts<N> &, const Src &) const { return true; }
   __device__ static const Src *src(const Args &a) { return a.colIn; }
+  __device__ static Src load(const Args &a, uint32_t b) { return a.colIn[b]; }
   vec4<N> ca;
   N mx, my, mz, mw;
   int nn;
@@ -378,8 +380,10 @@ template <typename N, bool FAST> struct LambdaOp {
   };
   static constexpr bool kNeedsCandidateType = false;
   static constexpr bool kFilter = true;
+  static constexpr bool kTileable = true;
   __device__ bool near(const StepConsts<N> &c, const Src &pb) const { return maybe_within_h<N>(pa, pb, c.h2filter); }
   __device__ static const Src *src(const Args &a) { return a.pstar; }
+  __device__ static Src load(const Args &a, uint32_t b) { return a.pstar[b]; }
   vec4<N> pa;
   N mass, gx, gy, gz, rho;
   __device__ bool begin(const StepConsts<N> &c, const Args &a, uint32_t i) {
@@ -432,8 +436,10 @@ template <typename N, bool FAST> struct DeltaOp {
   };
   static constexpr bool kNeedsCandidateType = false;
   static constexpr bool kFilter = true;
+  static constexpr bool kTileable = true;
   __device__ bool near(const StepConsts<N> &c, const Src &pb) const { return maybe_within_h<N>(pa, pb, c.h2filter); }
   __device__ static const Src *src(const Args &a) { return a.pstarIn; }
+  __device__ static Src load(const Args &a, uint32_t b) { return a.pstarIn[b]; }
   vec4<N> pa;
   N ax, ay, az;
   __device__ bool begin(const StepConsts<N> &c, const Args &a, uint32_t i) {
@@ -479,6 +485,137 @@ template <typename N, bool FAST> struct DeltaOp {
   }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Opt-in extras named by the north star but ABSENT from the reference (only their constants survive,
+// sph_constants.h:13-14; SURVEY finding 3): vorticity confinement and XSPH viscosity after Macklin &
+// Mueller 2013 (eq. 15-17), applied to the post-solve velocity, Jacobi.  Parity unpinned: the only
+// checker is our own CPU restatement (oracle extras()).  Candidates need position AND velocity.
+// ------------------------------------------------------------------------------------------------
+template <typename N> struct PosVel {
+  vec4<N> p, v;
+};
+
+// omega_a = sum_b (v_b - v_a) x grad spiky(a, b)
+template <typename N, bool FAST> struct VorticityOp {
+  using Src = PosVel<N>;
+  struct Args {
+    const vec4<N> *pstar, *vel;
+    vec4<N> *omega;
+    const uint8_t *type;
+  };
+  static constexpr bool kNeedsCandidateType = false;
+  static constexpr bool kFilter = true;
+  static constexpr bool kTileable = false;
+  __device__ static Src load(const Args &a, uint32_t b) { return {a.pstar[b], a.vel[b]}; }
+  vec4<N> pa, va;
+  N wx, wy, wz;
+  __device__ bool near(const StepConsts<N> &c, const Src &b) const { return maybe_within_h<N>(pa, b.p, c.h2filter); }
+  __device__ bool begin(const StepConsts<N> &c, const Args &a, uint32_t i) {
+    wx = wy = wz = N(0);
+    if (c.hasObstacles && a.type[i] != 0) {
+      a.omega[i] = make_vec4<N>(N(0), N(0), N(0), N(0));
+      return false;
+    }
+    pa = a.pstar[i], va = a.vel[i];
+    return true;
+  }
+  __device__ void add(const StepConsts<N> &c, const Src &b) { add_bf(c, b); }
+  __device__ void add_bf(const StepConsts<N> &c, const Src &b) {
+    const auto g = pair_geom<N, FAST>(pa, b.p, c.h);
+    const N s = c.spikyFactor * g.hr2_over_r;
+    const N gx = g.inSpiky ? g.dx * s : N(0), gy = g.inSpiky ? g.dy * s : N(0), gz = g.inSpiky ? g.dz * s : N(0);
+    const N ux = b.v.x - va.x, uy = b.v.y - va.y, uz = b.v.z - va.z;
+    wx = wx + (uy * gz - uz * gy), wy = wy + (uz * gx - ux * gz), wz = wz + (ux * gy - uy * gx);
+  }
+  __device__ void end(const StepConsts<N> &, const Args &a, uint32_t i) { a.omega[i] = make_vec4<N>(wx, wy, wz, N(0)); }
+};
+
+// eta = sum_b grad spiky(a, b) |omega_b| ; v_a += (eta/|eta| x omega_a) * (VORTICITY_EPSILON * dt)
+template <typename N, bool FAST> struct VorticityForceOp {
+  using Src = PosVel<N>;  // .v carries omega
+  struct Args {
+    const vec4<N> *pstar, *omega, *velIn;
+    vec4<N> *velOut;
+    const uint8_t *type;
+  };
+  static constexpr bool kNeedsCandidateType = false;
+  static constexpr bool kFilter = true;
+  static constexpr bool kTileable = false;
+  __device__ static Src load(const Args &a, uint32_t b) { return {a.pstar[b], a.omega[b]}; }
+  vec4<N> pa, wa, va;
+  N ex, ey, ez;
+  __device__ bool near(const StepConsts<N> &c, const Src &b) const { return maybe_within_h<N>(pa, b.p, c.h2filter); }
+  __device__ bool begin(const StepConsts<N> &c, const Args &a, uint32_t i) {
+    ex = ey = ez = N(0);
+    va = a.velIn[i];
+    if (c.hasObstacles && a.type[i] != 0) {
+      a.velOut[i] = va;
+      return false;
+    }
+    pa = a.pstar[i], wa = a.omega[i];
+    return true;
+  }
+  __device__ void add(const StepConsts<N> &c, const Src &b) { add_bf(c, b); }
+  __device__ void add_bf(const StepConsts<N> &c, const Src &b) {
+    const auto g = pair_geom<N, FAST>(pa, b.p, c.h);
+    const N s = c.spikyFactor * g.hr2_over_r;
+    const N len = sqrt(b.v.x * b.v.x + b.v.y * b.v.y + b.v.z * b.v.z);
+    const N tx = (g.dx * s) * len, ty = (g.dy * s) * len, tz = (g.dz * s) * len;
+    ex += g.inSpiky ? tx : N(0), ey += g.inSpiky ? ty : N(0), ez += g.inSpiky ? tz : N(0);
+  }
+  __device__ void end(const StepConsts<N> &c, const Args &a, uint32_t i) {
+    const N len = sqrt(ex * ex + ey * ey + ez * ez);
+    vec4<N> v = va;
+    if (len > N(EPSILON)) {
+      const N inv = N(1) / len;
+      const N nx = ex * inv, ny = ey * inv, nz = ez * inv;
+      const N k = N(VORTICITY_EPSILON) * c.dt;
+      v.x = va.x + (ny * wa.z - nz * wa.y) * k, v.y = va.y + (nz * wa.x - nx * wa.z) * k,
+      v.z = va.z + (nx * wa.y - ny * wa.x) * k;
+    }
+    a.velOut[i] = v;
+  }
+};
+
+// v_a = v_a + C * sum_b (v_b - v_a) poly6(r)
+template <typename N, bool FAST> struct XsphOp {
+  using Src = PosVel<N>;
+  struct Args {
+    const vec4<N> *pstar, *velIn;
+    vec4<N> *velOut;
+    const uint8_t *type;
+  };
+  static constexpr bool kNeedsCandidateType = false;
+  static constexpr bool kFilter = true;
+  static constexpr bool kTileable = false;
+  __device__ static Src load(const Args &a, uint32_t b) { return {a.pstar[b], a.velIn[b]}; }
+  vec4<N> pa, va;
+  N ax, ay, az;
+  __device__ bool near(const StepConsts<N> &c, const Src &b) const { return maybe_within_h<N>(pa, b.p, c.h2filter); }
+  __device__ bool begin(const StepConsts<N> &c, const Args &a, uint32_t i) {
+    ax = ay = az = N(0);
+    va = a.velIn[i];
+    if (c.hasObstacles && a.type[i] != 0) {
+      a.velOut[i] = va;
+      return false;
+    }
+    pa = a.pstar[i];
+    return true;
+  }
+  __device__ void add(const StepConsts<N> &c, const Src &b) { add_bf(c, b); }
+  __device__ void add_bf(const StepConsts<N> &c, const Src &b) {
+    const auto g = pair_geom<N, FAST>(pa, b.p, c.h);
+    const N d = (c.h * c.h) - g.r * g.r;
+    const N w = g.inH ? c.poly6Factor * (d * d * d) : N(0);
+    ax = ax + (b.v.x - va.x) * w, ay = ay + (b.v.y - va.y) * w, az = az + (b.v.z - va.z) * w;
+  }
+  __device__ void end(const StepConsts<N> &, const Args &a, uint32_t i) {
+    vec4<N> v = va;
+    v.x = va.x + ax * N(C_XSPH), v.y = va.y + ay * N(C_XSPH), v.z = va.z + az * N(C_XSPH);
+    a.velOut[i] = v;
+  }
+};
+
 // One particle through the global-memory 27-cell walk.
 template <typename N, typename Op>
 __device__ inline void gather_one_global(const StepConsts<N> &c, const typename Op::Args &args,
@@ -486,18 +623,17 @@ __device__ inline void gather_one_global(const StepConsts<N> &c, const typename 
                                          uint32_t i) {
   Op op;
   if (!op.begin(c, args, i)) return;
-  const typename Op::Src *src = Op::src(args);
   if (Op::kNeedsCandidateType && c.hasObstacles) {
     for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) {
-      if (!(args.type[b] & 1)) op.add(c, src[b]);
+      if (!(args.type[b] & 1)) op.add(c, Op::load(args, b));
     });
   } else if (Op::kFilter) {  // lambda / delta: the branchy pair terms skip whole waves, keep one per trip
-    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { op.add(c, src[b]); });
+    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { op.add(c, Op::load(args, b)); });
   } else {
     for_each_candidate2(
-        key[i], table, c.tableN, [&](uint32_t b) { op.add(c, src[b]); },
+        key[i], table, c.tableN, [&](uint32_t b) { op.add(c, Op::load(args, b)); },
         [&](uint32_t b0, uint32_t b1) {
-          const typename Op::Src p0 = src[b0], p1 = src[b1];
+          const typename Op::Src p0 = Op::load(args, b0), p1 = Op::load(args, b1);
           op.add(c, p0);
           op.add(c, p1);
         });
@@ -803,7 +939,6 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
     if (SAVE) nbrCount[i] = 0;
     return;
   }
-  const typename Op::Src *src = Op::src(args);
   uint32_t nl = 0, written = 0;
   uint32_t *mine = SAVE ? nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK + tid : nullptr;
   auto drain = [&]() {
@@ -811,7 +946,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
     for (uint32_t q = 0; q < nl; ++q) {
       const uint32_t b = list[q * BLOCK + tid];
       if (SAVE && written + q < NBR_CAP) mine[(written + q) * BLOCK] = b;
-      op.add_bf(c, src[b]);
+      op.add_bf(c, Op::load(args, b));
     }
     written += nl;
     nl = 0;
@@ -819,7 +954,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
   // same walk as kernel A (lanes of one cell stay in lockstep => their candidate loads coalesce);
   // phase A only filters, phase B (drain) runs the exact pair terms for the survivors, in order
   for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) {
-    const bool hit = op.near(c, src[b]);
+    const bool hit = op.near(c, Op::load(args, b));
     list[nl * BLOCK + tid] = b;  // branch-free append: the slot is kept only on a hit
     nl += hit ? 1u : 0u;
     if (__any(nl == uint32_t(LMAX))) drain();  // every lane active here drains together
@@ -842,14 +977,13 @@ __global__ __launch_bounds__(BLOCK) void k_gather_from_lists(StepConsts<N> c, ty
   if (i >= c.n) return;
   Op op;
   if (!op.begin(c, args, i)) return;
-  const typename Op::Src *src = Op::src(args);
   const uint32_t cnt = nbrCount[i];
   if (cnt == NBR_OVERFLOW) {
-    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { op.add(c, src[b]); });
+    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { op.add(c, Op::load(args, b)); });
   } else {
     const uint32_t *mine = nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK + tid;
 #pragma unroll 2
-    for (uint32_t q = 0; q < cnt; ++q) op.add_bf(c, src[mine[q * BLOCK]]);
+    for (uint32_t q = 0; q < cnt; ++q) op.add_bf(c, Op::load(args, mine[q * BLOCK]));
   }
   op.end(c, args, i);
 }

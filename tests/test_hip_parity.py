@@ -237,6 +237,26 @@ def test_iteration_counts(pkg, oracle, iteration):
         o.step(q)
     assert_state_equal(s.download(), o.get_particles())
 
+@pytest.mark.parametrize("fp64", [False, True])
+@pytest.mark.parametrize("xsph,vort", [(1, 0), (0, 1), (1, 1)])
+def test_xsph_vorticity_bit_exact(pkg, oracle, fp64, xsph, vort):
+    """Opt-in extras the north star names but the reference lacks (only constants survive,
+    sph_constants.h:13-14): checked against OUR restatement only — parity unpinned."""
+    sc, side = get_scene(pkg, "dam8192", fp64)
+    s, o = mk(pkg, oracle, sc, fp64)
+    p, q = params_pair(pkg, oracle, side=side)
+    p.xsph, p.vorticity, q.xsph, q.vorticity = xsph, vort, xsph, vort
+    for frame in range(4):
+        s.step(p)
+        o.step(q)
+    assert_state_equal(s.download(), o.get_particles())
+    # and they do something: velocities differ from the plain solve
+    s0, _ = mk(pkg, oracle, sc, fp64)
+    p0, _ = params_pair(pkg, oracle, side=side)
+    s0.steps(p0, 4)
+    assert not np.array_equal(s0.download()["vel"], s.download()["vel"])
+
+
 # ------------------------------------------------------------------------------------------ B
 
 

@@ -211,6 +211,40 @@ def test_invariants_and_gs_jacobi_band(oracle):
     assert abs(cg - cj) / cg < 0.15, (cg, cj)
 
 
+def test_extras_are_opt_in_and_sane(oracle):
+    """XSPH / vorticity (absent from the reference; constants only, sph_constants.h:13-14): off by
+    default = reference behaviour; XSPH is a smoothing (velocity variance does not grow), a rigid
+    translation carries no vorticity force."""
+    s = oracle.scene_cubes(2048)
+    base = oracle.Oracle(False)
+    base.set_particles(**s)
+    p = oracle.make_params(threads=2)
+    for _ in range(5):
+        base.step(p)
+    st = base.get_particles()
+    outs = {}
+    for tag, kw in (("none", {}), ("xsph", {"xsph": 1}), ("vort", {"vorticity": 1})):
+        o = oracle.Oracle(False)
+        o.set_particles(**st)
+        o.step(oracle.make_params(threads=2, **kw))
+        outs[tag] = by_id(o.get_particles())
+    assert np.array_equal(outs["none"]["pos"], outs["xsph"]["pos"])  # extras touch velocities only
+    assert not np.array_equal(outs["none"]["vel"], outs["xsph"]["vel"])
+    assert outs["xsph"]["vel"].var() <= outs["none"]["vel"].var() * (1 + 1e-6)
+    # rigid translation: all velocities equal => omega = 0 => no vorticity force, XSPH is a no-op
+    st2 = {k: v.copy() for k, v in st.items()}
+    st2["vel"][:] = [1.0, -2.0, 0.5]
+    res = {}
+    for tag, kw in (("none", {}), ("both", {"xsph": 1, "vorticity": 1})):
+        o = oracle.Oracle(False)
+        o.set_particles(**st2)
+        q = oracle.make_params(threads=2, iteration=0, force=(0, 0, 0), **kw)
+        o.step(q)
+        res[tag] = by_id(o.get_particles())
+    # (finalise recomputes v from rounded positions, so "equal" velocities differ in the last bits)
+    assert np.abs(res["none"]["vel"] - res["both"]["vel"]).max() <= 1e-5
+
+
 def test_empty_and_single(oracle):
     o = oracle.Oracle(False)
     p = oracle.make_params()
