@@ -667,6 +667,7 @@ int pbf_create(const pbf_desc *desc, pbf_ctx **out) {
   ctx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = std::getenv("PBF_TILE_CAP")) ctx->tileCap = uint32_t(std::atoi(e));
   if (const char *e = std::getenv("PBF_GATHER")) ctx->gatherKind = std::atoi(e);
+  if (const char *e = std::getenv("PBF_REUSE_LISTS")) ctx->reuseLists = std::atoi(e) != 0;
   if (const char *e = std::getenv("PBF_LIST_MAX")) ctx->listMax = uint32_t(std::atoi(e));
   if ((e = hipSetDevice(ctx->device)) != hipSuccess) {
     g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);

@@ -353,7 +353,9 @@ template <typename N> struct DiffuseOp {
     mx += cb.x, my += cb.y, mz += cb.z, mw += cb.w;
     ++nn;
   }
-  __device__ void add_bf(const StepConsts<N> &c, const Src &cb) { add(c, cb); }
+  __device__ void add_bf(const StepConsts<N> &c, const Src &cb, bool valid = true) {
+    if (valid) add(c, cb);
+  }
   __device__ void end(const StepConsts<N> &c, const Args &a, uint32_t i) {
     vec4<N> out = ca;
     if (nn != 0) {
@@ -407,17 +409,18 @@ template <typename N, bool FAST> struct LambdaOp {
       rho += mass * (c.poly6Factor * (d * d * d));
     }
   }
-  __device__ void add_bf(const StepConsts<N> &c, const Src &pb) {
-    // branch-free form for the list drain: two consecutive calls form one basic block and their long
+  __device__ void add_bf(const StepConsts<N> &c, const Src &pb, bool valid = true) {
+    // branch-free form for the list drain (`valid` = false turns a padding entry into +0): two consecutive calls form one basic block and their long
     // sqrt / divide chains interleave.  An excluded pair contributes exactly +0 (a select, never a
     // multiply: r = 0 makes hr2_over_r infinite), which leaves every partial sum bit-identical.
     const auto g = pair_geom<N, FAST>(pa, pb, c.h);
     const N s = c.spikyFactor * g.hr2_over_r;
     const N tx = (g.dx * s) * N(RHO_RECIP), ty = (g.dy * s) * N(RHO_RECIP), tz = (g.dz * s) * N(RHO_RECIP);
-    gx += g.inSpiky ? tx : N(0), gy += g.inSpiky ? ty : N(0), gz += g.inSpiky ? tz : N(0);
+    const bool sp = g.inSpiky && valid, ih = g.inH && valid;
+    gx += sp ? tx : N(0), gy += sp ? ty : N(0), gz += sp ? tz : N(0);
     const N d = (c.h * c.h) - g.r * g.r;
     const N w = mass * (c.poly6Factor * (d * d * d));
-    rho += g.inH ? w : N(0);
+    rho += ih ? w : N(0);
   }
   __device__ void end(const StepConsts<N> &, const Args &a, uint32_t i) {
     const N norm2 = gx * gx + gy * gy + gz * gz;
@@ -463,7 +466,7 @@ template <typename N, bool FAST> struct DeltaOp {
       ax += (g.dx * s) * factor, ay += (g.dy * s) * factor, az += (g.dz * s) * factor;
     }
   }
-  __device__ void add_bf(const StepConsts<N> &c, const Src &pb) {
+  __device__ void add_bf(const StepConsts<N> &c, const Src &pb, bool valid = true) {
     // branch-free like LambdaOp::add_bf; outside the spiky support the gradient is exactly zero, so
     // corr / factor are irrelevant there and the select adds +0
     const auto g = pair_geom<N, FAST>(pa, pb, c.h);
@@ -474,7 +477,8 @@ template <typename N, bool FAST> struct DeltaOp {
     const N factor = (pa.w + pb.w + corr) / N(RHO);
     const N s = c.spikyFactor * g.hr2_over_r;
     const N tx = (g.dx * s) * factor, ty = (g.dy * s) * factor, tz = (g.dz * s) * factor;
-    ax += g.inSpiky ? tx : N(0), ay += g.inSpiky ? ty : N(0), az += g.inSpiky ? tz : N(0);
+    const bool sp = g.inSpiky && valid;
+    ax += sp ? tx : N(0), ay += sp ? ty : N(0), az += sp ? tz : N(0);
   }
   __device__ void end(const StepConsts<N> &c, const Args &a, uint32_t i) {
     N x = (pa.x + ax) * c.scale, y = (pa.y + ay) * c.scale, z = (pa.z + az) * c.scale;
@@ -520,7 +524,8 @@ template <typename N, bool FAST> struct VorticityOp {
     return true;
   }
   __device__ void add(const StepConsts<N> &c, const Src &b) { add_bf(c, b); }
-  __device__ void add_bf(const StepConsts<N> &c, const Src &b) {
+  __device__ void add_bf(const StepConsts<N> &c, const Src &b, bool valid = true) {
+    if (!valid) return;
     const auto g = pair_geom<N, FAST>(pa, b.p, c.h);
     const N s = c.spikyFactor * g.hr2_over_r;
     const N gx = g.inSpiky ? g.dx * s : N(0), gy = g.inSpiky ? g.dy * s : N(0), gz = g.inSpiky ? g.dz * s : N(0);
@@ -556,7 +561,8 @@ template <typename N, bool FAST> struct VorticityForceOp {
     return true;
   }
   __device__ void add(const StepConsts<N> &c, const Src &b) { add_bf(c, b); }
-  __device__ void add_bf(const StepConsts<N> &c, const Src &b) {
+  __device__ void add_bf(const StepConsts<N> &c, const Src &b, bool valid = true) {
+    if (!valid) return;
     const auto g = pair_geom<N, FAST>(pa, b.p, c.h);
     const N s = c.spikyFactor * g.hr2_over_r;
     const N len = sqrt(b.v.x * b.v.x + b.v.y * b.v.y + b.v.z * b.v.z);
@@ -603,7 +609,8 @@ template <typename N, bool FAST> struct XsphOp {
     return true;
   }
   __device__ void add(const StepConsts<N> &c, const Src &b) { add_bf(c, b); }
-  __device__ void add_bf(const StepConsts<N> &c, const Src &b) {
+  __device__ void add_bf(const StepConsts<N> &c, const Src &b, bool valid = true) {
+    if (!valid) return;
     const auto g = pair_geom<N, FAST>(pa, b.p, c.h);
     const N d = (c.h * c.h) - g.r * g.r;
     const N w = g.inH ? c.poly6Factor * (d * d * d) : N(0);
@@ -915,8 +922,10 @@ __device__ inline uint32_t neighbour_code(uint32_t xm, uint32_t ym, uint32_t zm,
 
 // Neighbour lists kept in HBM between the lambda and the delta launch of ONE solver iteration: both
 // see the same pStar, hence the same filtered candidates in the same order, so delta can skip the
-// 27-cell walk and the filter altogether.  Layout [block][slot][thread] (coalesced 1 KiB rows), at
-// most NBR_CAP slots per particle; a particle with more survivors is marked NBR_OVERFLOW and walks.
+// 27-cell walk and the filter altogether.  Layout [block][slot][thread]: the reader's loads are
+// coalesced 1 KiB rows (measured: [particle][slot] rows cost +50 % in the reader and more in the
+// writer; whole padded rows overflow — lanes fill at different times); at most NBR_CAP slots per
+// particle, a particle with more survivors is marked NBR_OVERFLOW and walks.
 constexpr uint32_t NBR_CAP = 64;
 constexpr uint32_t NBR_OVERFLOW = 0xFFFFFFFFu;
 
@@ -939,26 +948,47 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
     if (SAVE) nbrCount[i] = 0;
     return;
   }
+  // From here on control flow is WAVE-UNIFORM over the lanes that are left (loop conditions are
+  // __any votes): every drain is executed by all of them together.
   uint32_t nl = 0, written = 0;
   uint32_t *mine = SAVE ? nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK + tid : nullptr;
   auto drain = [&]() {
 #pragma unroll 2
-    for (uint32_t q = 0; q < nl; ++q) {
-      const uint32_t b = list[q * BLOCK + tid];
-      if (SAVE && written + q < NBR_CAP) mine[(written + q) * BLOCK] = b;
-      op.add_bf(c, Op::load(args, b));
+    for (uint32_t q = 0; __any(q < nl); ++q) {
+      const bool valid = q < nl;
+      const uint32_t b = valid ? list[q * BLOCK + tid] : i;
+      if (SAVE && valid && written + q < NBR_CAP) mine[(written + q) * BLOCK] = b;
+      op.add_bf(c, Op::load(args, b), valid);
     }
     written += nl;
     nl = 0;
   };
-  // same walk as kernel A (lanes of one cell stay in lockstep => their candidate loads coalesce);
-  // phase A only filters, phase B (drain) runs the exact pair terms for the survivors, in order
-  for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) {
-    const bool hit = op.near(c, Op::load(args, b));
-    list[nl * BLOCK + tid] = b;  // branch-free append: the slot is kept only on a hit
-    nl += hit ? 1u : 0u;
-    if (__any(nl == uint32_t(LMAX))) drain();  // every lane active here drains together
-  });
+  const Neigh nb = neigh_codes(key[i]);
+#pragma unroll 1
+  for (int dz = 0; dz < 3; ++dz)
+#pragma unroll 1
+    for (int dy = 0; dy < 3; ++dy) {
+      const uint32_t yz = nb.ys[dy] | nb.zs[dz];
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const uint32_t code = nb.xs[dx] | yz;
+        uint32_t start = 0, len = 0;
+        if (code < c.tableN) {  // sph.hpp:206-208
+          start = table[code];
+          len = ((code + 1u) < c.tableN ? table[code + 1u] : start) - start;
+        }
+        // phase A: filter only; lanes of one cell stay in lockstep, so their candidate loads coalesce
+        for (uint32_t t = 0; __any(t < len); ++t) {
+          if (t < len) {
+            const uint32_t b = start + t;
+            const bool hit = op.near(c, Op::load(args, b));
+            list[nl * BLOCK + tid] = b;  // branch-free append: the slot is kept only on a hit
+            nl += hit ? 1u : 0u;
+          }
+          if (__any(nl == uint32_t(LMAX))) drain();  // phase B: exact pair terms for the survivors, in order
+        }
+      }
+    }
   drain();
   if (SAVE) nbrCount[i] = written <= NBR_CAP ? written : NBR_OVERFLOW;
   op.end(c, args, i);
@@ -983,7 +1013,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_from_lists(StepConsts<N> c, ty
   } else {
     const uint32_t *mine = nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK + tid;
 #pragma unroll 2
-    for (uint32_t q = 0; q < cnt; ++q) op.add_bf(c, Op::load(args, mine[q * BLOCK]));
+    for (uint32_t q = 0; q < cnt; ++q) op.add_bf(c, Op::load(args, mine[q * BLOCK]), true);
   }
   op.end(c, args, i);
 }
