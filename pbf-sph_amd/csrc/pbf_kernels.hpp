@@ -935,7 +935,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
                                                         const uint32_t *__restrict__ table,
                                                         uint32_t *__restrict__ nbrList,
                                                         uint32_t *__restrict__ nbrCount) {
-  __shared__ uint32_t list[(Op::kFilter ? LMAX : 1) * BLOCK];
+  __shared__ uint32_t list[(Op::kFilter ? LMAX + 4 : 1) * BLOCK];  // +4: a trip appends up to WAYS past LMAX - 1
   const uint32_t tid = threadIdx.x;
   const uint32_t i = blockIdx.x * BLOCK + tid;
   if (i >= c.n) return;
@@ -971,21 +971,34 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
       const uint32_t yz = nb.ys[dy] | nb.zs[dz];
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
+        // (merging the x-adjacent pair 2m, 2m+1 into one range was measured: slower — odd and even x
+        // lanes of a wave then walk ranges of different length and fall out of lockstep)
         const uint32_t code = nb.xs[dx] | yz;
         uint32_t start = 0, len = 0;
         if (code < c.tableN) {  // sph.hpp:206-208
           start = table[code];
           len = ((code + 1u) < c.tableN ? table[code + 1u] : start) - start;
         }
-        // phase A: filter only; lanes of one cell stay in lockstep, so their candidate loads coalesce
-        for (uint32_t t = 0; __any(t < len); ++t) {
+        // phase A: filter only, WAYS candidates per trip (their loads are in flight together); lanes of
+        // one cell stay in lockstep, so their candidate loads coalesce
+        constexpr uint32_t WAYS = 4;
+        for (uint32_t t = 0; __any(t < len); t += WAYS) {
           if (t < len) {
-            const uint32_t b = start + t;
-            const bool hit = op.near(c, Op::load(args, b));
-            list[nl * BLOCK + tid] = b;  // branch-free append: the slot is kept only on a hit
-            nl += hit ? 1u : 0u;
+            uint32_t b[WAYS];
+            typename Op::Src cnd[WAYS];
+#pragma unroll
+            for (uint32_t w = 0; w < WAYS; ++w) {
+              b[w] = start + min(t + w, len - 1u);  // a tail slot re-reads the last candidate and is masked
+              cnd[w] = Op::load(args, b[w]);
+            }
+#pragma unroll
+            for (uint32_t w = 0; w < WAYS; ++w) {
+              const bool hit = (t + w < len) && op.near(c, cnd[w]);
+              list[nl * BLOCK + tid] = b[w];  // branch-free append: the slot is kept only on a hit
+              nl += hit ? 1u : 0u;
+            }
           }
-          if (__any(nl == uint32_t(LMAX))) drain();  // phase B: exact pair terms for the survivors, in order
+          if (__any(nl >= uint32_t(LMAX))) drain();  // phase B: exact pair terms for the survivors, in order
         }
       }
     }
