@@ -1025,8 +1025,16 @@ __global__ __launch_bounds__(BLOCK) void k_gather_from_lists(StepConsts<N> c, ty
     for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { op.add(c, Op::load(args, b)); });
   } else {
     const uint32_t *mine = nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK + tid;
-#pragma unroll 2
-    for (uint32_t q = 0; q < cnt; ++q) op.add_bf(c, Op::load(args, mine[q * BLOCK]), true);
+    for (uint32_t q = 0; q < cnt; q += 4) {  // four list entries and their candidates in flight per trip
+      uint32_t b[4];
+      typename Op::Src cnd[4];
+#pragma unroll
+      for (uint32_t w = 0; w < 4; ++w) b[w] = q + w < cnt ? mine[(q + w) * BLOCK] : i;
+#pragma unroll
+      for (uint32_t w = 0; w < 4; ++w) cnd[w] = Op::load(args, b[w]);
+#pragma unroll
+      for (uint32_t w = 0; w < 4; ++w) op.add_bf(c, cnd[w], q + w < cnt);
+    }
   }
   op.end(c, args, i);
 }
