@@ -166,6 +166,16 @@ def main():
         dom_ms, dom_calls = stage[dom]
         achieved = sb[dom] * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         bytes_step = (276 + 44 * args.solver_iter) if not args.fp64 else (528 + 88 * args.solver_iter)
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+        # WRITE_SIZE collected separately, 2 x FETCH gfx950 correction; profiles/r01_pmc_traffic.json) — only
+        # valid for the configuration those passes ran: 1 GPU, fp32, default particle count and math mode
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if world == 1 and not args.fp64 and args.particles == (1 << 20) and not args.fast_math and os.path.exists(tfile):
+            tag = {"sph-lambda": "LambdaOp", "sph-delta": "DeltaOp", "sph-diffuse": "DiffuseOp"}.get(dom)
+            for name, t in json.load(open(tfile)).items():
+                if tag and tag in name and "gather" in name:
+                    traffic = t["hbm_bytes_gfx950_corrected"]
         out = {
             "metric": "particle-steps/sec (1 M particles, 4 iters) + achieved HBM GB/s, 1/2/4/8 MI355X",
             "value": value,
@@ -188,7 +198,7 @@ def main():
                                       f"lambda/delta launch over RCCL ({backend}); box {world}x1x1 columns; "
                                       f"max rank load {imbalance:.2f}x mean"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_particle": sb[dom], "mean_launch_ms": dom_ms,
                          "launches_timed": dom_calls,
                          "whole_step_GBs": value * bytes_step / 1e9 / world,

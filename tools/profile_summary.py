@@ -51,6 +51,17 @@ def pmc(dirs, out):
         fh.write(allr.round(2).to_markdown(index=False))
         fh.write("\n")
     print(allr.round(2).to_string(index=False))
+    # machine-readable per-kernel HBM traffic (bench.py quotes it in roofline.traffic)
+    import json
+    piv = allr.pivot_table(index="Name", columns="Counter_Name", values="mean")
+    traffic = {}
+    for name, row in piv.iterrows():
+        f, w = row.get("FETCH_SIZE"), row.get("WRITE_SIZE")
+        if f == f and w == w:  # both present
+            traffic[name] = {"fetch_kib": float(f), "write_kib": float(w),
+                             "hbm_bytes_gfx950_corrected": float((2 * f + w) * 1024)}
+    with open(os.path.splitext(out)[0] + ".json", "w") as fh:
+        json.dump(traffic, fh, indent=1)
 
 
 if __name__ == "__main__":
