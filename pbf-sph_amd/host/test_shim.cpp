@@ -1,0 +1,107 @@
+// test_shim.cpp — exercises the host side of sph::hip_impl::Solver::advance() that the benchmark
+// driver never touches: sources, drains, queries, depletion, and advance() == resident stepping
+// (reference behaviour: src/omp/ompsph.hpp:91-126,167-186).  Prints "ok <name>" / "FAIL <name> ..."
+// lines; tests/test_cli_gpu.py runs it on a GPU.
+#include <cmath>
+#include <cstdio>
+#include <set>
+
+#include "hipsph.hpp"
+
+using T = size_t;
+using N = float;
+using P = sph::Particle<T, N, sph::vec>;
+using V3 = sph::vec<3, N>;
+using V4 = sph::vec<4, N>;
+
+static int failures = 0;
+#define CHECK(name, cond, ...)                  \
+  do {                                          \
+    if (cond) std::printf("ok %s\n", name);     \
+    else {                                      \
+      ++failures;                               \
+      std::printf("FAIL %s ", name);            \
+      std::printf(__VA_ARGS__);                 \
+      std::printf("\n");                        \
+    }                                           \
+  } while (0)
+
+int main() {
+  auto [mc, config, particles] = sph::simpleConfigWith2Cubes<T, N, sph::vec>(2048, 4, N(500));
+  (void)mc;
+  sph::hip_impl::Solver<T, N> solver(N(0.1));
+
+  {  // sources: floor(sqrt(rate)) x ceil(sqrt(rate)) particles per frame, spacing h*scale/2 (ompsph.hpp:93-105)
+    auto xs = particles;
+    sph::Scene<T, N, sph::vec> scene;
+    scene.sources.push_back({T(100777), V3(500, 300, 500), V3(0, 1, 0), V4(1, 0, 0, 1), N(16)});
+    scene.sources.push_back({T(100888), V3(200, 700, 800), V3(0, 0, 0), V4(0, 1, 0, 1), N(10)});
+    const size_t before = xs.size();
+    solver.advance(config, scene, xs);
+    size_t n777 = 0, n888 = 0;
+    for (const auto &p : xs) n777 += p.id == 100777, n888 += p.id == 100888;
+    CHECK("sources_count", xs.size() == before + 16 + 12 && n777 == 16 && n888 == 12, "size %zu n777 %zu n888 %zu",
+          xs.size(), n777, n888);
+    solver.advance(config, scene, xs);
+    CHECK("sources_accumulate", xs.size() == before + 2 * 28, "size %zu", xs.size());
+  }
+  {  // drains: fluid within `width` of the centre disappears, obstacles stay (ompsph.hpp:107-118)
+    auto xs = particles;
+    xs[0].type = sph::Type::Obstacle;
+    sph::Scene<T, N, sph::vec> scene;
+    scene.drains.push_back({T(1), xs[0].position, N(60), N(0)});
+    size_t expectGone = 0;
+    for (size_t i = 1; i < xs.size(); ++i) {
+      const V3 r = xs[i].position - xs[0].position;
+      expectGone += std::sqrt(r.x * r.x + r.y * r.y + r.z * r.z) < 60;
+    }
+    const size_t before = xs.size();
+    solver.advance(config, scene, xs);
+    bool obstacleKept = false;
+    for (const auto &p : xs) obstacleKept |= p.id == particles[0].id && p.type == sph::Type::Obstacle;
+    CHECK("drains", expectGone > 3 && xs.size() == before - expectGone && obstacleKept, "gone %zu size %zu->%zu", expectGone,
+          before, xs.size());
+  }
+  {  // queries: ids of the fluid particles in the query point's cell (ompsph.hpp:167-186); particles at rest
+    auto xs = particles;
+    auto still = config;
+    still.constantForce = V3(0, 0, 0);
+    still.iteration = 0;
+    sph::Scene<T, N, sph::vec> scene;
+    scene.queries.push_back({T(5), xs[100].position});
+    scene.queries.push_back({T(6), V3(990, 990, 990)});  // empty corner
+    const V3 q0 = xs[100].position;
+    const T id100 = xs[100].id;
+    auto cell = [&](const V3 &p, int ax) {
+      const N v = ax == 0 ? p.x : ax == 1 ? p.y : p.z;
+      return long((v / still.scale - (N(0) / still.scale - N(0.2))) / N(0.1));
+    };
+    std::set<T> expect;
+    for (const auto &p : xs)
+      if (cell(p.position, 0) == cell(q0, 0) && cell(p.position, 1) == cell(q0, 1) && cell(p.position, 2) == cell(q0, 2))
+        expect.insert(p.id);
+    const auto res = solver.advance(still, scene, xs);
+    std::set<T> got(res.queries[0].neighbours.begin(), res.queries[0].neighbours.end());
+    CHECK("queries", res.queries.size() == 2 && res.queries[0].id == 5 && got == expect && got.count(id100) == 1 &&
+                         res.queries[1].neighbours.empty(),
+          "got %zu expect %zu", got.size(), expect.size());
+  }
+  {  // depletion (ompsph.hpp:122-126)
+    std::vector<P> none;
+    const auto res = solver.advance(config, {}, none);
+    CHECK("depleted", none.empty() && res.mesh.vs.empty() && res.queries.empty(), "-");
+  }
+  {  // advance() per frame == device-resident stepping, bit for bit
+    auto a = particles, b = particles;
+    for (int f = 0; f < 3; ++f) solver.advance(sph::applyMotionSinXCosZ(config, f), {}, a);
+    sph::hip_impl::Solver<T, N> resident(N(0.1));
+    resident.upload(b);
+    for (int f = 0; f < 3; ++f) resident.step(sph::applyMotionSinXCosZ(config, f));
+    resident.download(b);
+    bool same = a.size() == b.size();
+    for (size_t i = 0; same && i < a.size(); ++i) same = a[i] == b[i];
+    CHECK("advance_equals_resident", same, "sizes %zu %zu", a.size(), b.size());
+  }
+  std::printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
+  return failures ? 1 : 0;
+}

@@ -67,3 +67,12 @@ def test_cli_flags(tmp_path):
     assert "Final Particle count : 8192" in txt and "fp64" in txt and "sph-lambda" in txt
     r = subprocess.run([BIN, "-i", "omp"], capture_output=True, text=True)
     assert r.returncode != 0 and "not part of this build" in r.stderr
+
+
+def test_cpp_shim_sources_drains_queries():
+    """host/test_shim.cpp: the parts of hip_impl::Solver::advance() the benchmark never exercises
+    (sources, drains, queries, depletion — ompsph.hpp:91-126,167-186) and advance() == resident."""
+    r = subprocess.run([os.path.join(ROOT, "pbf-sph_amd", "test_shim")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout + r.stderr
+    for name in ("sources_count", "sources_accumulate", "drains", "queries", "depleted", "advance_equals_resident"):
+        assert f"ok {name}" in r.stdout, r.stdout
