@@ -110,6 +110,7 @@ _SIGS = {
                                   C.c_int]),
     "pbf_reset_stage_times": (C.c_int, [C.c_void_p]),
     "pbf_reserve": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "pbf_slab_configure": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "pbf_slab_record_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "pbf_slab_migrate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "pbf_slab_add_migrants": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),

@@ -76,6 +76,7 @@ template <typename N> struct StepConsts {
   uint32_t tableN;  // Morton(extent) (sph.hpp:240)
   uint32_t nWells;
   uint32_t hasObstacles;
+  uint32_t xoff;  // slab mode: keys use the x cell coordinate minus xoff (rank-local, compact table); 0 otherwise
 };
 
 }  // namespace pbf

@@ -67,6 +67,10 @@ struct pbf_ctx {
   // slab decomposition (pbf_slab_*): bookkeeping of what was sent / received this step
   DevBuf slotOf, selCounts, selTotals, ghostSrcL, ghostSrcR;
   bool slabActive = false, realObstacles = false;
+  bool slabConfigured = false;  // pbf_slab_configure: rank-local x frame for the keys (compact table per rank)
+  pbf_slab_cut slabCut{0, 0, 0, 0};
+  uint32_t xoff = 0;
+  int32_t shiftL = 0, shiftR = 0;
   size_t reserve = 0;        // pbf_reserve: capacity kept for migrants and ghost copies
   uint32_t nOwned = 0, sentL = 0, sentR = 0, gotL = 0, gotR = 0;
   DevBuf nbrList, nbrCount;  // neighbour lists handed from the lambda launch to the delta launch (NBR_CAP per particle)
@@ -185,6 +189,12 @@ template <typename N> int make_consts(pbf_ctx *ctx, const pbf_params *p, StepCon
     if (ext[i] > 1023)
       return fail(ctx, PBF_ERR_INVALID, "grid extent exceeds the 10-bit-per-axis Morton range (curves.h:72-88)");
     ctx->extent[i] = ext[i];
+  }
+  c.xoff = 0;
+  if (ctx->slabConfigured) {  // keys live in this rank's x frame: columns [xoff, right ghost column]
+    c.xoff = ctx->xoff;
+    const uint64_t hi = ctx->slabCut.has_right ? std::min<uint64_t>(ext[0], uint64_t(ctx->slabCut.xhi) + 1) : ext[0];
+    ext[0] = hi > ctx->xoff ? hi - ctx->xoff : 1;
   }
   c.tableN = morton_encode(uint32_t(ext[0]), uint32_t(ext[1]), uint32_t(ext[2]));  // sph.hpp:240
   if (c.tableN == 0) return fail(ctx, PBF_ERR_INVALID, "empty grid (max_bound <= min_bound?)");
@@ -899,7 +909,9 @@ int run_select(pbf_ctx *ctx, const pbf_slab_cut *cut, void *sendL, void *sendR, 
   if (int rc = ensure(ctx, ctx->ghostSrcR, size_t(std::max(cap, 1u)) * 4)) return rc;
   totals[0] = totals[1] = totals[2] = 0;
   if (n == 0) return PBF_OK;
-  SlabCut s{cut->xlo, cut->xhi, cut->has_left ? 1u : 0u, cut->has_right ? 1u : 0u};
+  const uint32_t xo = ctx->slabConfigured ? ctx->xoff : 0u;  // the keys' x frame
+  SlabCut s{cut->xlo - std::min(cut->xlo, xo), cut->xhi == 0xFFFFFFFFu ? cut->xhi : cut->xhi - std::min(cut->xhi, xo),
+            cut->has_left ? 1u : 0u, cut->has_right ? 1u : 0u};
   const int a = ctx->cur, b = 1 - a;
   uint32_t *counts = ctx->selCounts.as<uint32_t>(), *tot = ctx->selTotals.as<uint32_t>();
   hipLaunchKernelGGL((k_sel_count<MODE>), dim3(nb), dim3(BLOCK), 0, ctx->stream, n, s, ctx->key[a].as<const uint32_t>(),
@@ -935,7 +947,7 @@ template <typename N> int slab_add_migrants(pbf_ctx *ctx, const void *rL, uint32
   if (nL + nR)
     hipLaunchKernelGGL((k_append_migrants<N>), grid_for(nL + nR), dim3(BLOCK), 0, ctx->stream, uint32_t(ctx->n),
                        static_cast<const MigrantRec<N> *>(rL), nL, static_cast<const MigrantRec<N> *>(rR), nR,
-                       arrays<N>(ctx, ctx->cur, ctx->pcur));
+                       ctx->shiftL, ctx->shiftR, arrays<N>(ctx, ctx->cur, ctx->pcur));
   LAUNCH_CHECK(ctx);
   ctx->n += nL + nR;
   ctx->nOwned = uint32_t(ctx->n);
@@ -956,7 +968,7 @@ template <typename N> int slab_add_ghosts(pbf_ctx *ctx, const void *rL, uint32_t
   if (nL + nR)
     hipLaunchKernelGGL((k_append_ghosts<N>), grid_for(nL + nR), dim3(BLOCK), 0, ctx->stream, uint32_t(ctx->n),
                        static_cast<const GhostRec<N> *>(rL), nL, static_cast<const GhostRec<N> *>(rR), nR,
-                       arrays<N>(ctx, ctx->cur, ctx->pcur));
+                       ctx->shiftL, ctx->shiftR, arrays<N>(ctx, ctx->cur, ctx->pcur));
   ctx->gotL = nL, ctx->gotR = nR;
   ctx->n += nL + nR;
   if (nL + nR) ctx->hasObstacles = true;  // "special" particles exist: the kernels must look at type[]
@@ -1026,6 +1038,24 @@ int pbf_reserve(pbf_ctx *ctx, size_t capacity) {
   if (!ctx) return PBF_ERR_INVALID;
   if (ctx->n && capacity > ctx->cap) return fail(ctx, PBF_ERR_STATE, "pbf_reserve must precede pbf_upload");
   ctx->reserve = capacity;
+  return PBF_OK;
+}
+int pbf_slab_configure(pbf_ctx *ctx, const pbf_slab_cut *cut, uint32_t left_xlo, uint32_t right_xlo) {
+  if (!ctx) return PBF_ERR_INVALID;
+  if (!cut) {  // back to the global x frame
+    ctx->slabConfigured = false, ctx->xoff = 0, ctx->shiftL = ctx->shiftR = 0;
+    return PBF_OK;
+  }
+  if (cut->xhi <= cut->xlo) return fail(ctx, PBF_ERR_INVALID, "empty slab");
+  // frame origin = the left ghost column (one left of the first owned column); rank 0 keeps the padding columns
+  auto origin = [](uint32_t xlo, bool hasLeft) { return hasLeft && xlo > 0 ? xlo - 1u : 0u; };
+  ctx->slabCut = *cut;
+  ctx->xoff = origin(cut->xlo, cut->has_left != 0);
+  // a neighbour's records arrive keyed in ITS frame: x_mine = x_theirs + their_origin - my_origin
+  ctx->shiftL = int32_t(origin(left_xlo, left_xlo > 0)) - int32_t(ctx->xoff);
+  ctx->shiftR = int32_t(origin(right_xlo, true)) - int32_t(ctx->xoff);
+  ctx->slabConfigured = true;
+  ctx->sorted = false;
   return PBF_OK;
 }
 size_t pbf_slab_record_bytes(const pbf_ctx *ctx, int kind) {

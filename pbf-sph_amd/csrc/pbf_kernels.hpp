@@ -58,7 +58,7 @@ __global__ __launch_bounds__(BLOCK) void k_predict(StepConsts<N> c, const vec4<N
     pz = (v.z * c.dt) + (p.z / c.scale);
   }
   pstar[i] = make_vec4<N>(px, py, pz, N(0));
-  const uint32_t k = morton_encode(static_cast<uint32_t>(cell_coord((px - c.minExtent[0]) / c.h)),
+  const uint32_t k = morton_encode(static_cast<uint32_t>(cell_coord((px - c.minExtent[0]) / c.h)) - c.xoff,
                                    static_cast<uint32_t>(cell_coord((py - c.minExtent[1]) / c.h)),
                                    static_cast<uint32_t>(cell_coord((pz - c.minExtent[2]) / c.h)));
   key[i] = k;

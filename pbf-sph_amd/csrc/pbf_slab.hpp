@@ -155,29 +155,37 @@ __global__ __launch_bounds__(BLOCK) void k_sel_emit(uint32_t n, SlabCut s, Parti
   }
 }
 
+// A record keyed in the sender's rank-local x frame is re-keyed into ours: x' = x + shift (cells).
+__device__ inline uint32_t shift_key_x(uint32_t key, int32_t shift) {
+  const uint32_t x = (compact10(key) + uint32_t(shift)) & 1023u;
+  return (key & ~MORTON_X) | spread10(x);
+}
+
 template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_append_migrants(uint32_t at, const MigrantRec<N> *__restrict__ recvL,
                                                            uint32_t nL, const MigrantRec<N> *__restrict__ recvR,
-                                                           uint32_t nR, ParticleArrays<N> dst) {
+                                                           uint32_t nR, int32_t shiftL, int32_t shiftR,
+                                                           ParticleArrays<N> dst) {
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
   if (j >= nL + nR) return;
   const MigrantRec<N> r = j < nL ? recvL[j] : recvR[j - nL];
   const uint32_t d = at + j;
   dst.pos4[d] = r.pos4, dst.vel4[d] = r.vel4, dst.col4[d] = r.col4, dst.pstar[d] = r.pstar;
-  dst.id[d] = r.id, dst.type[d] = uint8_t(r.type), dst.key[d] = r.key;
+  dst.id[d] = r.id, dst.type[d] = uint8_t(r.type), dst.key[d] = shift_key_x(r.key, j < nL ? shiftL : shiftR);
 }
 
 template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_append_ghosts(uint32_t at, const GhostRec<N> *__restrict__ recvL,
                                                          uint32_t nL, const GhostRec<N> *__restrict__ recvR,
-                                                         uint32_t nR, ParticleArrays<N> dst) {
+                                                         uint32_t nR, int32_t shiftL, int32_t shiftR,
+                                                         ParticleArrays<N> dst) {
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
   if (j >= nL + nR) return;
   const GhostRec<N> r = j < nL ? recvL[j] : recvR[j - nL];
   const uint32_t d = at + j;
   const vec4<N> zero = make_vec4<N>(N(0), N(0), N(0), N(0));
   dst.pos4[d] = zero, dst.vel4[d] = zero, dst.col4[d] = r.col4, dst.pstar[d] = r.pstar;
-  dst.id[d] = ~uint64_t(0), dst.type[d] = uint8_t(r.type), dst.key[d] = r.key;
+  dst.id[d] = ~uint64_t(0), dst.type[d] = uint8_t(r.type), dst.key[d] = shift_key_x(r.key, j < nL ? shiftL : shiftR);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_count_keys(uint32_t n, uint32_t tableN, const uint32_t *__restrict__ key,

@@ -4,7 +4,9 @@ torch.distributed (backend "nccl"); the same driver runs on CPU tensors with "gl
 The reference is single-device — this layer has no counterpart there; its
 correctness statement is "N ranks == 1 rank".  Layout: rank g owns the cell columns
 [cuts[g], cuts[g+1]) of the GLOBAL grid (every rank passes the same bounds) plus a one-cell layer of
-copies ("ghosts") of its x-neighbours' boundary columns.  Per step:
+copies ("ghosts") of its x-neighbours' boundary columns.  Keys are kept in a rank-local x frame
+(origin = the left ghost column; records are re-keyed on arrival), so each rank's grid table covers its
+slab only — constant size under weak scaling instead of Morton(global extent).  Per step:
 
     predict ─ migrate ⇄ add_migrants ─ ghosts ⇄ add_ghosts ─ sort ─ diffuse ─
     K × { lambda ─ pack ⇄ unpack ─ delta ─ pack ⇄ unpack } ─ finalise ─ finish
@@ -67,6 +69,11 @@ class HipEngine:
         from . import capi
         return capi.SlabCut(cut[0], cut[1], int(cut[2]), int(cut[3]))
 
+    def configure(self, cut, left_xlo, right_xlo):
+        """Rank-local key frame: the grid table then covers the slab + ghost columns only."""
+        c = self._cut(cut)
+        self.s._chk(self.L.pbf_slab_configure(self.ctx, C.byref(c), left_xlo, right_xlo), "pbf_slab_configure")
+
     def predict(self, p):
         self.s.stage("predict", p)
 
@@ -123,7 +130,7 @@ class SlabSolver:
         # under the "gloo" backend for tests; production uses "nccl" = RCCL straight from device memory)
         self.e, self.dist, self.rank, self.nranks = engine, dist, rank, nranks
         self.stage_via_host = stage_via_host
-        self.set_cuts(cuts)
+        self.set_cuts(cuts)  # also switches the engine to rank-local keys
         self.cap = int(cap_records)
         big = max(engine.record_bytes(REC_MIGRANT), engine.record_bytes(REC_GHOST))
         self.send = [engine.alloc(self.cap * big) for _ in range(2)]
@@ -140,6 +147,9 @@ class SlabSolver:
         self.left = self.rank - 1 if self.rank > 0 else None
         self.right = self.rank + 1 if self.rank + 1 < self.nranks else None
         self.cut = (self.cuts[self.rank], self.cuts[self.rank + 1], self.left is not None, self.right is not None)
+        if self.nranks > 1:
+            self.e.configure(self.cut, self.cuts[self.rank - 1] if self.left is not None else 0,
+                             self.cuts[self.rank + 1] if self.right is not None else 0)
 
     # -- neighbour exchange -----------------------------------------------------------------------
     def _exchange(self, send_bytes, recv_bytes):

@@ -10,6 +10,22 @@ REC_MIGRANT, REC_GHOST, REC_FIELD = 0, 1, 2
 GHOST = 2
 
 
+def spread10(x):
+    x = x & 0x3FF
+    x = (x | (x << 16)) & 0x030000FF
+    x = (x | (x << 8)) & 0x0300F00F
+    x = (x | (x << 4)) & 0x030C30C3
+    x = (x | (x << 2)) & 0x09249249
+    return x
+
+
+def shift_key_x(keys, shift):
+    """Re-key into another rank-local x frame (mirrors shift_key_x in csrc/pbf_slab.hpp)."""
+    k = keys.astype(np.int64)
+    x = (compact10(k) + shift) & 1023
+    return ((k & ~0x09249249) | spread10(x)).astype(np.uint64)
+
+
 def compact10(v):
     v = v & 0x09249249
     v = (v | (v >> 2)) & 0x030C30C3
@@ -36,6 +52,7 @@ class OracleEngine:
         self.src = [np.zeros(0, np.int64), np.zeros(0, np.int64)]
         self.got = [0, 0]
         self.slot_of = None
+        self.xoff, self.shift = 0, [0, 0]
 
     # -- plumbing ----------------------------------------------------------------------------------
     def alloc(self, nbytes):
@@ -43,6 +60,14 @@ class OracleEngine:
 
     def record_bytes(self, kind):
         return {REC_MIGRANT: self.mig_dt, REC_GHOST: self.gho_dt, REC_FIELD: self.fld_dt}[kind].itemsize
+
+    def configure(self, cut, left_xlo, right_xlo):
+        origin = lambda xlo, has_left: xlo - 1 if has_left and xlo > 0 else 0  # noqa: E731
+        self.xoff = origin(cut[0], cut[2])
+        self.shift = [origin(left_xlo, left_xlo > 0) - self.xoff, origin(right_xlo, True) - self.xoff]
+
+    def _local(self, cut):
+        return cut[0] - min(cut[0], self.xoff), cut[1] - min(cut[1], self.xoff), cut[2], cut[3]
 
     def upload(self, **sc):
         self.o.set_particles(**sc)
@@ -89,9 +114,11 @@ class OracleEngine:
     def predict(self, p):
         self.q = self._oparams(p)
         self.o.predict(self.q)
+        if self.xoff:  # keys in the rank-local x frame, like k_predict with StepConsts::xoff
+            self.o.set_scratch(shift_key_x(self.o.keys(), -self.xoff), None, None)
 
     def migrate(self, cut, send_l, send_r, cap):
-        xlo, xhi, has_l, has_r = cut
+        xlo, xhi, has_l, has_r = self._local(cut)
         st = self._state()
         cx = compact10(st["key"].astype(np.int64))
         ghost = (st["type"] & GHOST) != 0
@@ -111,15 +138,17 @@ class OracleEngine:
 
     def add_migrants(self, recv_l, n_l, recv_r, n_r):
         st = self._state()
-        for buf, n in ((recv_l, n_l), (recv_r, n_r)):
+        for side, (buf, n) in enumerate(((recv_l, n_l), (recv_r, n_r))):
             if n:
                 rec = self._read(buf, self.mig_dt, n)
-                st = self._cat(st, {k: rec[k].copy() for k in st})
+                add = {k: rec[k].copy() for k in st}
+                add["key"] = shift_key_x(add["key"], self.shift[side])
+                st = self._cat(st, add)
         self._set(st)
         self.n_owned_ = len(st["id"])
 
     def ghosts(self, cut, send_l, send_r, cap):
-        xlo, xhi, has_l, has_r = cut
+        xlo, xhi, has_l, has_r = self._local(cut)
         st = self._state()
         cx = compact10(st["key"].astype(np.int64))
         sel = [np.flatnonzero((cx == xlo) & has_l), np.flatnonzero((cx + 1 == xhi) & has_r)]
@@ -135,12 +164,13 @@ class OracleEngine:
 
     def add_ghosts(self, recv_l, n_l, recv_r, n_r):
         st = self._state()
-        for buf, n in ((recv_l, n_l), (recv_r, n_r)):
+        for side, (buf, n) in enumerate(((recv_l, n_l), (recv_r, n_r))):
             if n:
                 rec = self._read(buf, self.gho_dt, n)
                 add = {"id": np.full(n, 2 ** 64 - 1, np.uint64), "type": rec["type"].copy(),
                        "mass": np.zeros(n, self.fdt), "pos": np.zeros((n, 3), self.fdt),
-                       "vel": np.zeros((n, 3), self.fdt), "colour": rec["colour"].copy(), "key": rec["key"].copy(),
+                       "vel": np.zeros((n, 3), self.fdt), "colour": rec["colour"].copy(),
+                       "key": shift_key_x(rec["key"], self.shift[side]),
                        "pstar": rec["pstar"].copy(), "lam": rec["lam"].copy()}
                 st = self._cat(st, add)
         self.got = [n_l, n_r]
