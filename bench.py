@@ -95,8 +95,14 @@ def main():
     backend = os.environ.get("PBF_BENCH_BACKEND", "nccl")  # "gloo": rehearsal with several ranks on ONE GPU
     if world == 1 or backend == "nccl":
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_slab = os.environ.get("PBF_BENCH_FORCE_SLAB") == "1"  # rehearsal: slab driver + RCCL set-up with ONE rank
+    if world > 1 or force_slab:
         import torch.distributed as dist
+        if force_slab and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -110,7 +116,7 @@ def main():
     n = len(scene["id"])
     p = pkg.default_params(args.solver_iter, side)
     drv = None
-    if world == 1:
+    if world == 1 and not force_slab:
         solver = pkg.Solver(h=0.1, fp64=args.fp64, device=local_rank, flags=flags)
         solver.upload(**scene)
         run = lambda k: solver.steps(p, k)  # noqa: E731
