@@ -79,6 +79,7 @@ struct pbf_ctx {
   DevBuf bricks, brickCtl;  // non-empty brick list; brickCtl = {nActive, ticket[kTickets]}
   uint32_t gatherSeq = 0;   // which ticket word the next persistent gather launch uses
   int numCUs = 256;
+  uint32_t timingMask = 0xFFFFFFFFu;  // option "timing_mask": which stages PBF_FLAG_STAGE_TIMING brackets with events
   uint32_t padLds = 0;      // option "pad_lds": occupancy limiter for k_gather_global
   int gatherKind = 1;       // 0 = global walk (k_gather_global), 1 = filtered lists (default), 2 = persistent LDS bricks
   uint32_t tileCap = 0, listMax = 0;  // 0 = defaults (env PBF_TILE_CAP / PBF_LIST_MAX override)
@@ -271,7 +272,8 @@ struct StageTimer {
   pbf_ctx *ctx;
   EventPair ep{};
   bool on;
-  StageTimer(pbf_ctx *c, int stage) : ctx(c), on((c->desc.flags & PBF_FLAG_STAGE_TIMING) != 0) {
+  StageTimer(pbf_ctx *c, int stage)
+      : ctx(c), on((c->desc.flags & PBF_FLAG_STAGE_TIMING) != 0 && ((c->timingMask >> stage) & 1u) != 0) {
     if (!on) return;
     ep.a = get_event(ctx), ep.b = get_event(ctx), ep.stage = stage;
     (void)hipEventRecord(ep.a, ctx->stream);
@@ -630,6 +632,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   else if (n == "gather") ctx->gatherKind = int(value);
   else if (n == "tile_cap") ctx->tileCap = uint32_t(value);
   else if (n == "reuse_lists") ctx->reuseLists = value != 0;
+  else if (n == "timing_mask") ctx->timingMask = uint32_t(value);
   else if (n == "pad_lds") ctx->padLds = uint32_t(value);
   else return fail(ctx, PBF_ERR_INVALID, "unknown option " + n);
   return PBF_OK;
