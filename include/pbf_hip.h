@@ -79,7 +79,7 @@ void pbf_destroy(pbf_ctx *ctx);
 const char *pbf_last_error(const pbf_ctx *ctx);
 int pbf_abi_version(void);
 /* Tuning / diagnostic knobs (no reference counterpart): "gather" (0 global walk, 1 filtered lists, 2 LDS bricks),
- * "list_max", "tile_cap", "reuse_lists", "timing_mask" (bit i = stage i of pbf_stage_times is bracketed with events).
+ * "list_max", "tile_cap", "reuse_lists", "fuse_diffuse", "timing_mask" (bit i = stage i of pbf_stage_times is bracketed with events).
  * Unknown names return PBF_ERR_INVALID. */
 int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value);
 

@@ -76,6 +76,9 @@ struct pbf_ctx {
   DevBuf nbrList, nbrCount;  // neighbour lists handed from the lambda launch to the delta launch (NBR_CAP per particle)
   bool nbrValid = false;     // the lists describe pstar[pcur] as it is now
   bool reuseLists = true;    // option "reuse_lists"
+  bool fuseDiffuse = false;  // option "fuse_diffuse": pbf_step folds the diffuse walk into the first lambda launch
+                             // (bit-identical; measured 2 % SLOWER at 1 M — the colour loads stall the filter loop — so off)
+  bool fuseDiffuseNow = false;
   DevBuf bricks, brickCtl;  // non-empty brick list; brickCtl = {nActive, ticket[kTickets]}
   uint32_t gatherSeq = 0;   // which ticket word the next persistent gather launch uses
   int numCUs = 256;
@@ -466,6 +469,28 @@ template <typename N> int stage_lambda(pbf_ctx *ctx, const pbf_params *p) {
   const bool lists = ctx->gatherKind == 1 && ctx->reuseLists && !(ctx->desc.flags & PBF_FLAG_NO_LDS);
   const GatherMode save = lists ? GATHER_SAVE_LISTS : GATHER_PLAIN;
   ctx->nbrValid = lists;
+  if (lists && ctx->fuseDiffuseNow) {  // pbf_step: the colour diffusion rides on this launch's walk
+    ctx->fuseDiffuseNow = false;
+    const int d = 1 - s;
+    typename DiffuseOp<N>::Args xa{ctx->col4[s].as<const vec4<N>>(), ctx->col4[d].as<vec4<N>>(),
+                                   ctx->type[s].as<const uint8_t>()};
+    const uint32_t *key = ctx->key[s].as<const uint32_t>(), *table = ctx->table.as<const uint32_t>();
+    uint32_t *nl = ctx->nbrList.as<uint32_t>(), *nc = ctx->nbrCount.as<uint32_t>();
+    if (ctx->fast) {
+      typename LambdaOp<N, true>::Args a{ctx->pstar[ctx->pcur].as<vec4<N>>(), ctx->pos4[s].as<const vec4<N>>(),
+                                         ctx->type[s].as<const uint8_t>()};
+      hipLaunchKernelGGL((k_gather_lists<N, LambdaOp<N, true>, 16, true, DiffuseOp<N>>), grid_for(ctx->n), dim3(BLOCK), 0,
+                         ctx->stream, c, a, key, table, nl, nc, xa);
+    } else {
+      typename LambdaOp<N, false>::Args a{ctx->pstar[ctx->pcur].as<vec4<N>>(), ctx->pos4[s].as<const vec4<N>>(),
+                                          ctx->type[s].as<const uint8_t>()};
+      hipLaunchKernelGGL((k_gather_lists<N, LambdaOp<N, false>, 16, true, DiffuseOp<N>>), grid_for(ctx->n), dim3(BLOCK), 0,
+                         ctx->stream, c, a, key, table, nl, nc, xa);
+    }
+    LAUNCH_CHECK(ctx);
+    std::swap(ctx->col4[s], ctx->col4[d]);
+    return PBF_OK;
+  }
   if (ctx->fast) {
     typename LambdaOp<N, true>::Args args{ctx->pstar[ctx->pcur].as<vec4<N>>(), ctx->pos4[s].as<const vec4<N>>(),
                                           ctx->type[s].as<const uint8_t>()};
@@ -546,7 +571,13 @@ template <typename N> int step_impl(pbf_ctx *ctx, const pbf_params *p) {
   if (ctx->n == 0) return PBF_OK;  // "Particles depleted" (ompsph.hpp:122-126)
   if (int rc = stage_predict<N>(ctx, p)) return rc;
   if (int rc = stage_sort<N>(ctx, p)) return rc;
-  if (int rc = stage_diffuse<N>(ctx, p)) return rc;
+  // diffuse (ompsph.hpp:188-207) visits exactly the candidates of the first lambda launch: fuse the two walks
+  const bool fuse = ctx->fuseDiffuse && p->iteration > 0 && ctx->gatherKind == 1 && ctx->reuseLists &&
+                    !(ctx->desc.flags & PBF_FLAG_NO_LDS);
+  if (!fuse) {
+    if (int rc = stage_diffuse<N>(ctx, p)) return rc;
+  }
+  ctx->fuseDiffuseNow = fuse;
   for (uint64_t it = 0; it < p->iteration; ++it) {
     if (int rc = stage_lambda<N>(ctx, p)) return rc;
     if (int rc = stage_delta<N>(ctx, p)) return rc;
@@ -632,6 +663,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   else if (n == "gather") ctx->gatherKind = int(value);
   else if (n == "tile_cap") ctx->tileCap = uint32_t(value);
   else if (n == "reuse_lists") ctx->reuseLists = value != 0;
+  else if (n == "fuse_diffuse") ctx->fuseDiffuse = value != 0;
   else if (n == "timing_mask") ctx->timingMask = uint32_t(value);
   else if (n == "pad_lds") ctx->padLds = uint32_t(value);
   else return fail(ctx, PBF_ERR_INVALID, "unknown option " + n);

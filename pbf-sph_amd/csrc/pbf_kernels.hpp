@@ -3,6 +3,8 @@
 // reproduces; the decomposition (device counting sort, packed pStar+lambda, Jacobi buffers) is ours.
 #pragma once
 
+#include <type_traits>
+
 #include "pbf_common.hpp"
 
 namespace pbf {
@@ -929,12 +931,19 @@ __device__ inline uint32_t neighbour_code(uint32_t xm, uint32_t ym, uint32_t zm,
 constexpr uint32_t NBR_CAP = 64;
 constexpr uint32_t NBR_OVERFLOW = 0xFFFFFFFFu;
 
-template <typename N, typename Op, int LMAX, bool SAVE = false>
+// A second, unfiltered op can ride along on the same walk (FUSE_DIFFUSE: the colour diffusion needs
+// exactly the candidates the first lambda launch of a step visits, in the same order).
+struct NoExtra {
+  struct Args {};
+};
+template <typename N, typename Op, int LMAX, bool SAVE = false, typename Extra = NoExtra>
 __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typename Op::Args args,
                                                         const uint32_t *__restrict__ key,
                                                         const uint32_t *__restrict__ table,
                                                         uint32_t *__restrict__ nbrList,
-                                                        uint32_t *__restrict__ nbrCount) {
+                                                        uint32_t *__restrict__ nbrCount,
+                                                        typename Extra::Args xargs = {}) {
+  constexpr bool FUSED = !std::is_same<Extra, NoExtra>::value;
   __shared__ uint32_t list[(Op::kFilter ? LMAX + 4 : 1) * BLOCK];  // +4: a trip appends up to WAYS past LMAX - 1
   const uint32_t tid = threadIdx.x;
   const uint32_t i = blockIdx.x * BLOCK + tid;
@@ -944,6 +953,8 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
     return;
   }
   Op op;
+  Extra extra;
+  if constexpr (FUSED) extra.begin(c, xargs, i);  // skips exactly when op.begin() does (type != 0) and copies through
   if (!op.begin(c, args, i)) {
     if (SAVE) nbrCount[i] = 0;
     return;
@@ -997,6 +1008,11 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
               list[nl * BLOCK + tid] = b[w];  // branch-free append: the slot is kept only on a hit
               nl += hit ? 1u : 0u;
             }
+            if constexpr (FUSED) {
+#pragma unroll
+              for (uint32_t w = 0; w < WAYS; ++w)
+                if (t + w < len && !(c.hasObstacles && (xargs.type[b[w]] & 1))) extra.add(c, Extra::load(xargs, b[w]));
+            }
           }
           if (__any(nl >= uint32_t(LMAX))) drain();  // phase B: exact pair terms for the survivors, in order
         }
@@ -1005,6 +1021,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
   drain();
   if (SAVE) nbrCount[i] = written <= NBR_CAP ? written : NBR_OVERFLOW;
   op.end(c, args, i);
+  if constexpr (FUSED) extra.end(c, xargs, i);
 }
 
 // List-driven gather: the survivors recorded by the previous k_gather_lists<.., SAVE> launch on the

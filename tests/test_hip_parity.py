@@ -133,6 +133,21 @@ def test_free_running_bit_exact(pkg, oracle, scene, fp64, variant):
             assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
 
 
+def test_fused_diffuse_bit_exact(pkg, oracle):
+    """Option fuse_diffuse: the colour diffusion rides on the first lambda launch's walk (same candidates,
+    same order) — identical bits, obstacles included."""
+    sc, side = get_scene(pkg, "cubes8192", False)
+    sc = {k: v.copy() for k, v in sc.items()}
+    sc["type"][::11] = 1
+    s, o = mk(pkg, oracle, sc, False)
+    s.set_option("fuse_diffuse", 1)
+    p, q = params_pair(pkg, oracle, side=side)
+    for frame in range(4):
+        s.step(p)
+        o.step(q)
+    assert_state_equal(s.download(), o.get_particles())
+
+
 def test_moving_box_bit_exact(pkg, oracle, variant):
     """benchmark.cpp:33,47: every frame runs with applyMotionSinXCosZ(param, frame); the grid (and
     its table length) moves with the box."""
