@@ -320,8 +320,8 @@ template <typename N> __device__ inline bool maybe_within_h(const vec4<N> &a, co
 // ------------------------------------------------------------------------------------------------
 // The three 27-cell gather stages as "ops": begin(i) loads particle a (false = nothing to do),
 // add(b) folds one candidate in the reference's visiting order, end(i) stores the result.
-// Both gather kernels below (global-memory walk and LDS-tiled walk) run the SAME op code in the
-// SAME candidate order, so their results are bit-identical to each other and to the oracle.
+// All gather kernels below (global walk, filtered lists + list-driven, LDS bricks) run the SAME op
+// code in the SAME candidate order, so their results are bit-identical to each other and to the oracle.
 // ------------------------------------------------------------------------------------------------
 
 // diffuse (ompsph.hpp:188-207), Jacobi like the OpenCL kernel (ocl/oclsph_kernel.h:67-93)
@@ -651,9 +651,9 @@ __device__ inline void gather_one_global(const StepConsts<N> &c, const typename 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Gather kernel A — one thread per particle, candidates straight from global memory (L1/L2).
-// The simple form: used for A/B comparison (PBF_FLAG_NO_LDS), for diffuse when obstacles exist, and
-// as the in-kernel fallback of kernel B.
+// Gather kernel "global" (option gather = 0) — one thread per particle, candidates straight from global memory (L1/L2).
+// The simple form: used for A/B comparison (PBF_FLAG_NO_LDS / option gather = 0) and as the
+// in-kernel fallback of the brick kernel (pile-ups beyond the LDS tile, diffuse with obstacles).
 // ------------------------------------------------------------------------------------------------
 template <typename N, typename Op>
 __global__ __launch_bounds__(BLOCK) void k_gather_global(StepConsts<N> c, typename Op::Args args,
@@ -665,104 +665,14 @@ __global__ __launch_bounds__(BLOCK) void k_gather_global(StepConsts<N> c, typena
 }
 
 // ------------------------------------------------------------------------------------------------
-// Gather kernel B — LDS-tiled.  One workgroup owns a Morton-aligned brick of 4 x 4 x BZ cells:
+// Gather kernel "bricks" (option gather = 2) — LDS bricks.  One workgroup owns a Morton-aligned brick of 4 x 4 x BZ cells:
 // 16*BZ consecutive Morton codes, i.e. ONE contiguous run of sorted particles.  It stages the
 // brick's 6 x 6 x (BZ+2) halo of cells into LDS once — cell start/end from the grid table, then the
 // candidates' 16-byte (fp32) records — laid out x-fastest, so that for any home cell the three
 // x-adjacent neighbour cells are one contiguous LDS run: a particle walks 9 runs instead of 27 cell
 // ranges, in exactly the reference's order (sph.hpp:220-234).  Each candidate record is fetched
-// from L2/HBM ~3.4x (BZ=4) per launch instead of ~100x through L1.
-//   LDS: [0, 4*(HALO+1)) run offsets | [.., +4*HALO) global starts | 16-byte aligned tile[cap]
-// A brick whose halo holds more than `cap` records (piles at walls) falls back to the global walk.
-// Blocks >= nBricks sweep the particles that lie in no cell (key >= tableN, sph.hpp:206).
-// ------------------------------------------------------------------------------------------------
-template <int BZ> struct Brick {
-  static constexpr int HOME = 16 * BZ;            // Morton codes per brick
-  static constexpr int HZ = BZ + 2;               // halo depth in z
-  static constexpr int HALO = 36 * HZ;            // 6 x 6 x (BZ+2) cells
-  static constexpr int HDR = ((2 * HALO + 1) * 4 + 15) / 16 * 16;  // header bytes, keeps the tile 16-B aligned
-};
-
-template <typename N, typename Op, int BZ>
-__global__ __launch_bounds__(BLOCK) void k_gather_tiled(StepConsts<N> c, typename Op::Args args,
-                                                        const uint32_t *__restrict__ key,
-                                                        const uint32_t *__restrict__ table, uint32_t nBricks,
-                                                        uint32_t cap) {
-  using B = Brick<BZ>;
-  using Src = typename Op::Src;
-  extern __shared__ __align__(16) unsigned char smem[];
-  uint32_t *off = reinterpret_cast<uint32_t *>(smem);  // [HALO + 1]
-  uint32_t *gstart = off + B::HALO + 1;                // [HALO]
-  Src *tile = reinterpret_cast<Src *>(smem + B::HDR);
-  const uint32_t tid = threadIdx.x;
-
-  if (blockIdx.x >= nBricks) {  // particles in no cell: they still gather from their 27 neighbour codes
-    const uint32_t stride = (gridDim.x - nBricks) * BLOCK;
-    for (uint32_t i = table[c.tableN] + (blockIdx.x - nBricks) * BLOCK + tid; i < c.n; i += stride)
-      gather_one_global<N, Op>(c, args, key, table, i);
-    return;
-  }
-
-  const uint32_t code0 = blockIdx.x * B::HOME;
-  const uint32_t hs = table[code0];
-  const uint32_t he = table[min(code0 + uint32_t(B::HOME), c.tableN)];
-  if (hs == he) return;  // empty brick (uniform across the workgroup)
-
-  // ---- phase 1: the halo's cell ranges and their exclusive scan --------------------------------
-  const uint32_t bx = compact10(code0), by = compact10(code0 >> 1), bz = compact10(code0 >> 2);
-  uint32_t cnt = 0;
-  if (tid < B::HALO) {
-    const uint32_t lx = tid % 6, ly = (tid / 6) % 6, lz = tid / 36;
-    // +-1 wraps modulo 1024 exactly like curves.h's encode keeps the low 10 bits
-    const uint32_t code = morton_encode((bx + lx - 1u) & 1023u, (by + ly - 1u) & 1023u, (bz + lz - 1u) & 1023u);
-    uint32_t s = 0, e = 0;
-    if (code < c.tableN) {  // sph.hpp:206-208
-      s = table[code];
-      e = (code + 1u) < c.tableN ? table[code + 1u] : s;
-    }
-    gstart[tid] = s;
-    cnt = e - s;
-  }
-  uint32_t total;
-  const uint32_t ex = block_excl_scan(cnt, &total);
-  if (tid < B::HALO) off[tid] = ex;
-  if (tid == 0) off[B::HALO] = total;
-  __syncthreads();
-
-  const Src *src = Op::src(args);
-  const bool tiled = total <= cap && !(Op::kNeedsCandidateType && c.hasObstacles);
-  if (tiled) {
-    // ---- phase 2: stage the candidates (one halo cell per thread; a cell is one or two cache lines)
-    if (tid < B::HALO) {
-      const uint32_t s = gstart[tid], o = off[tid];
-      for (uint32_t j = 0; j < cnt; ++j) tile[o + j] = src[s + j];
-    }
-    __syncthreads();
-    // ---- phase 3: every home particle walks its 9 x-runs out of LDS -----------------------------
-    for (uint32_t i = hs + tid; i < he; i += BLOCK) {
-      Op op;
-      if (!op.begin(c, args, i)) continue;
-      const uint32_t k = key[i];
-      const uint32_t hx = (k & 1u) | ((k >> 2) & 2u);         // bits 0, 3
-      const uint32_t hy = ((k >> 1) & 1u) | ((k >> 3) & 2u);  // bits 1, 4
-      const uint32_t hz = BZ == 4 ? (((k >> 2) & 1u) | ((k >> 4) & 2u)) : ((k >> 2) & 1u);  // bits 2, (5)
-#pragma unroll 1
-      for (uint32_t dz = 0; dz < 3; ++dz)
-#pragma unroll 1
-        for (uint32_t dy = 0; dy < 3; ++dy) {
-          const uint32_t l0 = ((hz + dz) * 6u + (hy + dy)) * 6u + hx;
-          const uint32_t s = off[l0], e = off[l0 + 3];
-          for (uint32_t j = s; j < e; ++j) op.add(c, tile[j]);
-        }
-      op.end(c, args, i);
-    }
-  } else {
-    for (uint32_t i = hs + tid; i < he; i += BLOCK) gather_one_global<N, Op>(c, args, key, table, i);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Gather kernel C — kernel B made persistent and filtered.
+// from L2/HBM ~3.4x (BZ=4) per launch instead of ~180x through L1.  A brick whose halo holds more
+// than `cap` records (piles at walls) falls back to the global walk.
 //   * persistent workgroups pull bricks from a device-side list of NON-EMPTY bricks through an
 //     atomic ticket (k_brick_list builds the list during the sort stage), so the ~90 % of bricks
 //     that hold no fluid never cost a launch slot; the loop ends when the ticket passes the list
@@ -783,6 +693,13 @@ __global__ __launch_bounds__(BLOCK) void k_brick_list(const uint32_t *__restrict
   const uint32_t s = table[b * home], e = table[min((b + 1u) * home, tableN)];
   if (e > s) active[atomicAdd(nActive, 1u)] = b;  // order is arbitrary: it only schedules, never reorders sums
 }
+
+template <int BZ> struct Brick {
+  static constexpr int HOME = 16 * BZ;            // Morton codes per brick
+  static constexpr int HZ = BZ + 2;               // halo depth in z
+  static constexpr int HALO = 36 * HZ;            // 6 x 6 x (BZ+2) cells
+  static constexpr int HDR = ((2 * HALO + 1) * 4 + 15) / 16 * 16;  // header bytes, keeps the tile 16-B aligned
+};
 
 template <int BZ> struct Brick2 : Brick<BZ> {
   static constexpr int HDR2 = ((2 * Brick<BZ>::HALO + 1 + 1) * 4 + 15) / 16 * 16;  // + the ticket word
@@ -903,8 +820,9 @@ __global__ __launch_bounds__(THREADS) void k_gather_bricks(StepConsts<N> c, type
 }
 
 // ------------------------------------------------------------------------------------------------
-// Gather kernel D — one lane per particle, candidates from global memory (L1/L2), two phases:
-//   A  every lane walks its 27 cell ranges like kernel A but only applies the conservative
+// Gather kernel "lists" (option gather = 1, the default) — one lane per particle, candidates from
+// global memory (L1/L2), two phases:
+//   A  every lane walks its 27 cell ranges like the global kernel but only applies the conservative
 //      maybe_within_h filter (3 sub + 3 fma + cmp); survivors' global indices go to a per-lane list
 //      in LDS ([slot][thread], 4-byte);
 //   B  whenever an active lane's list is full — and once at the end — the lanes drain their lists

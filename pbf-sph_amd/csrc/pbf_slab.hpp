@@ -1,7 +1,8 @@
 // pbf_slab.hpp — device side of the multi-GPU slab decomposition (no reference counterpart: the
 // reference is single-device).  The domain is cut into slabs of whole cell columns
-// along x; every rank keeps the GLOBAL Morton keys and a table of the global size, so all the
-// single-GPU kernels run unchanged.  What is added here:
+// along x; the cell geometry is the global one (every rank passes the same bounds), keys may live in
+// a rank-local x frame (pbf_slab_configure: compact per-rank table), and all the single-GPU kernels
+// run unchanged.  What is added here:
 //   * a deterministic 3-pass "select" (count / scan / emit) that, in array order,
 //       mode MIGRATE: compacts the particles that stay, and packs those whose cell column left
 //                     the slab into wire records for the left / right neighbour (ghosts of the
