@@ -826,20 +826,11 @@ __global__ __launch_bounds__(THREADS) void k_gather_bricks(StepConsts<N> c, type
 //      maybe_within_h filter (3 sub + 3 fma + cmp); survivors' global indices go to a per-lane list
 //      in LDS ([slot][thread], 4-byte);
 //   B  whenever an active lane's list is full — and once at the end — the lanes drain their lists
-//      through the exact pair terms (IEEE sqrt / divide), in visiting order.  Rejected candidates contribute exactly +0, so
-//      results are bit-identical to the plain walk.
+//      through the exact pair terms (IEEE sqrt / divide), in visiting order.  Rejected candidates
+//      contribute exactly +0, so results are bit-identical to the plain walk.
 // No tiles, no bricks: occupancy is set by the list alone (LMAX x 1 KiB per 256 threads), and sparse
 // splash regions cost the same per particle as the dense column.
 // ------------------------------------------------------------------------------------------------
-__device__ inline uint32_t neighbour_code(uint32_t xm, uint32_t ym, uint32_t zm, uint32_t ci) {
-  // ci = dx + 3 dy + 9 dz in the reference's order (sph.hpp:220-234); dilated +-1 per axis
-  const uint32_t dx = ci % 3u, dy = (ci / 3u) % 3u, dz = ci / 9u;
-  const uint32_t x = dx == 0 ? (xm - 1u) & MORTON_X : dx == 1 ? xm : ((xm | ~MORTON_X) + 1u) & MORTON_X;
-  const uint32_t y = dy == 0 ? (ym - 2u) & MORTON_Y : dy == 1 ? ym : ((ym | ~MORTON_Y) + 2u) & MORTON_Y;
-  const uint32_t z = dz == 0 ? (zm - 4u) & MORTON_Z : dz == 1 ? zm : ((zm | ~MORTON_Z) + 4u) & MORTON_Z;
-  return x | y | z;
-}
-
 // Neighbour lists kept in HBM between the lambda and the delta launch of ONE solver iteration: both
 // see the same pStar, hence the same filtered candidates in the same order, so delta can skip the
 // 27-cell walk and the filter altogether.  Layout [block][slot][thread]: the reader's loads are

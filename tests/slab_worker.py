@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--iteration", type=int, default=4)
     ap.add_argument("--cuts", default="even")
+    ap.add_argument("--fp64", action="store_true")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -31,9 +32,9 @@ def main():
     from pbf_sph_amd import slab
 
     if a.scene.startswith("cubes"):
-        sc, side = pkg.scene_cubes(int(a.scene[5:])), 1000.0
+        sc, side = pkg.scene_cubes(int(a.scene[5:]), a.fp64), 1000.0
     else:
-        sc, side = pkg.scene_dambreak(int(a.scene[3:]))
+        sc, side = pkg.scene_dambreak(int(a.scene[3:]), a.fp64)
     p = pkg.default_params(a.iteration, side)
     if a.cuts == "even":
         cuts = slab.even_cuts(world, side)
@@ -47,12 +48,12 @@ def main():
     cap = len(sc["id"])
     if a.engine == "oracle":
         from slab_engines import OracleEngine
-        eng = OracleEngine(False, device_pow=True)
+        eng = OracleEngine(a.fp64, device_pow=True)
         eng.upload(**part)
         get = eng.download
         stage = False
     else:
-        s = pkg.Solver(h=0.1, device=0)
+        s = pkg.Solver(h=0.1, fp64=a.fp64, device=0)
         s._chk(s.L.pbf_reserve(s.ctx, cap), "pbf_reserve")
         s.upload(**part)
         eng = slab.HipEngine(s, torch, torch.device("cuda", 0))

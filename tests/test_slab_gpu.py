@@ -34,6 +34,17 @@ def test_hip_slabs_bit_exact_vs_oracle_slabs(pkg, tmp_path, world, cuts):
     assert d.max() <= 2e-2 and d.mean() <= 1e-4, (d.max(), d.mean())
 
 
+def test_hip_slabs_fp64_bit_exact(pkg, tmp_path):
+    args = ("--scene", "cubes2048", "--steps", "4", "--cuts", "x:210", "--fp64")
+    hip = launch(2, str(tmp_path / "hip"), "--engine", "hip", *args)
+    ora = launch(2, str(tmp_path / "ora"), "--engine", "oracle", *args)
+    for r in range(2):
+        assert hip[r]["pos"].dtype == np.float64
+        for k in ("id", "pos", "vel", "colour", "type"):
+            assert np.array_equal(hip[r][k], ora[r][k]), (r, k)
+        assert int(hip[r]["ghosts"]) > 0
+
+
 def test_hip_slabs_migration(pkg, tmp_path):
     args = ("--scene", "dam8192", "--steps", "30", "--iteration", "2", "--cuts", "x:150")
     hip = launch(2, str(tmp_path / "hip"), "--engine", "hip", *args)
