@@ -134,6 +134,19 @@ int pbf_grid_extent(const pbf_ctx *ctx, uint64_t extent[3], double min_extent[3]
 int pbf_stage_times(pbf_ctx *ctx, const char **names, double *mean_ms, uint64_t *calls, int cap);
 int pbf_reset_stage_times(pbf_ctx *ctx);
 
+/* ---- marching-cubes surface (reference: config.surface, src/sph.hpp:82-95,102; src/omp/ompsph.hpp:277-477) ---
+ * Runs on the state the last pbf_step left (its grid table is still valid): scalar field on a lattice of
+ * floor(extent * resolution) + 1 nodes per axis, triangles per cube, emission in cube order.
+ * pbf_surface returns the triangle count; pbf_download_mesh copies 3 vertices per triangle:
+ * vs / ns = 9 values of N per triangle, cs = 12 (the reference's ColouredMesh, src/sph.hpp:105-112). */
+typedef struct pbf_mc_params {
+  double resolution, isolevel, particle_size, particle_influence; /* sph::McParams */
+} pbf_mc_params;
+int pbf_surface(pbf_ctx *ctx, const pbf_params *params, const pbf_mc_params *mc, uint64_t *n_triangles);
+int pbf_download_mesh(pbf_ctx *ctx, void *vs, void *ns, void *cs);
+/* the lattice of the last pbf_surface: sample[3] nodes per axis, 4 + 4 values of N per node {v, normal} {colour} */
+int pbf_read_lattice(pbf_ctx *ctx, uint64_t sample[3], void *pn, void *c);
+
 /* ---- multi-GPU: slab decomposition along x (no reference counterpart: it is single-device) ------
  * One process per GPU.  Every rank uses the GLOBAL grid (same pbf_params bounds), owns the cell columns
  * [xlo, xhi) and keeps a one-cell layer of COPIES ("ghosts", type bit PBF_TYPE_GHOST) of its x-neighbours'

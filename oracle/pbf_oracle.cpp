@@ -17,6 +17,8 @@
 
 #include "pbf_oracle.h"
 
+#include "mc_tables.h"
+
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -141,6 +143,11 @@ template <typename N> struct Oracle final : pbf_oracle {
   std::array<uint64_t, 3> extent{};
   V3<N> minExtent{};
   N lastH = N(0.1);  // h of the last predict(), for candidate_stats
+  // marching cubes (ompsph.hpp:277-477)
+  std::array<uint64_t, 3> sample{};
+  std::vector<V4<N>> latticePN, latticeC;
+  std::vector<V3<N>> meshV, meshN;
+  std::vector<V4<N>> meshC;
   bool pow4 = false;
 
   size_t n() const { return id.size(); }
@@ -429,6 +436,111 @@ template <typename N> struct Oracle final : pbf_oracle {
     v.swap(vnew);
   }
 
+
+  // ---- marching-cubes surface (ompsph.hpp:277-477).  glm's fastDistance / fastLength / fastNormalize
+  // (gtx/fast_square_root, absent offline) are approximations without a bit contract; restated with the
+  // exact sqrt.  Triangles are emitted in cube order (the reference appends through an atomic counter,
+  // i.e. in no particular order); the case tables are oracle/mc_tables.h (generated, see tools/gen_mc_tables.py).
+  int mc_field(const pbf_oracle_params &c, const pbf_oracle_mc &m) {
+    const N h = N(c.h), scale = N(c.scale), res = N(m.resolution);
+    const N particleSize = N(m.particle_size), particleInfluence = N(m.particle_influence);
+    for (int k = 0; k < 3; ++k) sample[k] = static_cast<uint64_t>(std::floor(N(extent[k]) * res)) + 1;  // :283-284
+    const size_t latticeN = sample[0] * sample[1] * sample[2];
+    latticePN.assign(latticeN, V4<N>{N(0), N(0), N(0), N(0)});
+    latticeC.assign(latticeN, V4<N>{N(0), N(0), N(0), N(0)});
+    const N step = h / res, threshold = h * scale * 1;
+    const uint64_t tn = table.size();
+    foreach_1d(c.threads, latticeN, [&](size_t idx) {
+      const size_t x = idx / (sample[1] * sample[2]), y = (idx / sample[2]) % sample[1], z = idx % sample[2];
+      const V3<N> pos{N(x), N(y), N(z)};
+      const V3<N> a = (minExtent + (pos * step)) * scale;
+      const uint64_t zIndex = mortonEncode(uint64_t(pos.x / res), uint64_t(pos.y / res), uint64_t(pos.z / res));
+      const uint64_t zX = mortonDecode(zIndex, 0), zY = mortonDecode(zIndex, 1), zZ = mortonDecode(zIndex, 2);
+      if (zX == extent[0] && zY == extent[1] && zZ == extent[2]) return;  // :300-303
+      auto cl = [](int v, int hi) { return uint64_t(std::min(std::max(v, 0), hi)); };
+      const uint64_t xs[3] = {cl(int(zX) - 1, int(extent[0]) - 1), zX, cl(int(zX) + 1, int(extent[0]) - 1)};
+      const uint64_t ys[3] = {cl(int(zY) - 1, int(extent[1]) - 1), zY, cl(int(zY) + 1, int(extent[1]) - 1)};
+      const uint64_t zs[3] = {cl(int(zZ) - 1, int(extent[2]) - 1), zZ, cl(int(zZ) + 1, int(extent[2]) - 1)};
+      N v = 0;
+      V3<N> normal{N(0), N(0), N(0)};
+      V4<N> colourAcc{N(0), N(0), N(0), N(0)};
+      size_t nNeighbours = 0;
+      for (int dz = 0; dz < 3; ++dz)
+        for (int dy = 0; dy < 3; ++dy)
+          for (int dx = 0; dx < 3; ++dx) {  // :312-325, clamped cells may repeat at the domain faces
+            const uint64_t off = mortonEncode(xs[dx], ys[dy], zs[dz]);
+            if (off >= tn) continue;
+            const uint64_t s0 = table[off], e0 = (off + 1) < tn ? table[off + 1] : s0;
+            for (uint64_t b = s0; b < e0; ++b) {
+              if ((type[b] & 1) || (type[b] & 2)) continue;
+              const V3<N> l = this->pos[b] - a;
+              const N len = std::sqrt(dot(l, l));
+              if (!(len < threshold)) continue;
+              const N denominator = std::pow(len, particleInfluence);
+              v += (particleSize / denominator);
+              normal = normal + (l / denominator) * ((-particleInfluence) * particleSize);
+              colourAcc = {colourAcc.x + colour[b].x, colourAcc.y + colour[b].y, colourAcc.z + colour[b].z,
+                           colourAcc.w + colour[b].w};
+              nNeighbours++;
+            }
+          }
+      normal = normal * (N(1) / std::sqrt(dot(normal, normal)));
+      latticePN[idx] = {v, normal.x, normal.y, normal.z};
+      const N nn = N(nNeighbours);
+      latticeC[idx] = {colourAcc.x / nn, colourAcc.y / nn, colourAcc.z / nn, colourAcc.w / nn};
+    });
+    return 0;
+  }
+
+  int mc_emit(const pbf_oracle_params &c, const pbf_oracle_mc &m, uint64_t *nTriangles) {
+    const N h = N(c.h), scale = N(c.scale), res = N(m.resolution), isolevel = N(m.isolevel);
+    const N step = h / res;
+    static const uint64_t CUBE[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+    static const int EDGE[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+    meshV.clear(), meshN.clear(), meshC.clear();
+    if (sample[0] < 2 || sample[1] < 2 || sample[2] < 2) {
+      *nTriangles = 0;
+      return 0;
+    }
+    const uint64_t rx = sample[0] - 1, ry = sample[1] - 1, rz = sample[2] - 1;
+    for (uint64_t i = 0; i < rx * ry * rz; ++i) {
+      const uint64_t px = i / (ry * rz), py = (i / rz) % ry, pz = i % rz;  // utils::to3d
+      N values[8];
+      V3<N> offs[8], nrm[8];
+      V4<N> cols[8];
+      unsigned ci = 0;
+      for (int k = 0; k < 8; ++k) {
+        const uint64_t ox = px + CUBE[k][0], oy = py + CUBE[k][1], oz = pz + CUBE[k][2];
+        const size_t idx = ox * sample[1] * sample[2] + oy * sample[2] + oz;
+        const V4<N> point = latticePN[idx];
+        values[k] = point.x;
+        offs[k] = (minExtent + (V3<N>{N(ox), N(oy), N(oz)} * step)) * scale;
+        nrm[k] = {point.y, point.z, point.w};
+        cols[k] = latticeC[idx];
+        if (values[k] < isolevel) ci |= 1u << k;
+      }
+      if (kMcEdgeTable[ci] == 0) continue;
+      V3<N> ts[12], ns[12];
+      V4<N> cs[12];
+      for (int e = 0; e < 12; ++e)
+        if (kMcEdgeTable[ci] & (1u << e)) {
+          const int f = EDGE[e][0], t = EDGE[e][1];
+          const N w = (isolevel - values[f]) / (values[t] - values[f]);  // utils::scale
+          auto mix = [&](N a, N b) { return a * (N(1) - w) + b * w; };
+          ts[e] = {mix(offs[f].x, offs[t].x), mix(offs[f].y, offs[t].y), mix(offs[f].z, offs[t].z)};
+          ns[e] = {mix(nrm[f].x, nrm[t].x), mix(nrm[f].y, nrm[t].y), mix(nrm[f].z, nrm[t].z)};
+          cs[e] = {mix(cols[f].x, cols[t].x), mix(cols[f].y, cols[t].y), mix(cols[f].z, cols[t].z),
+                   mix(cols[f].w, cols[t].w)};
+        }
+      for (int k = 0; kMcTriTable[ci][k] != 255; ++k) {
+        const int e = kMcTriTable[ci][k];
+        meshV.push_back(ts[e]), meshN.push_back(ns[e]), meshC.push_back(cs[e]);
+      }
+    }
+    *nTriangles = meshV.size() / 3;
+    return 0;
+  }
+
   int finalise(const pbf_oracle_params &c) {
     // ompsph.hpp:256-264
     const size_t cnt = n();
@@ -680,6 +792,41 @@ void pbf_oracle_motion_offset(int fp64, uint64_t frame, double out[3]) {
   out[0] = fp64 ? ox : double(float(ox));
   out[1] = 0.0;
   out[2] = fp64 ? oz : double(float(oz));
+}
+
+int pbf_oracle_surface(pbf_oracle *o, const pbf_oracle_params *p, const pbf_oracle_mc *m, uint64_t *n_triangles) {
+  return dispatch(o, [&](auto &s) {
+    s.mc_field(*p, *m);
+    return s.mc_emit(*p, *m, n_triangles);
+  });
+}
+int pbf_oracle_surface_from_lattice(pbf_oracle *o, const pbf_oracle_params *p, const pbf_oracle_mc *m,
+                                    const uint64_t sample[3], const void *pn, const void *c, uint64_t *n_triangles) {
+  return dispatch(o, [&](auto &s) {
+    using N = std::decay_t<decltype(s.mass[0])>;
+    for (int k = 0; k < 3; ++k) s.sample[k] = sample[k];
+    const size_t n = sample[0] * sample[1] * sample[2];
+    s.latticePN.resize(n), s.latticeC.resize(n);
+    std::memcpy(s.latticePN.data(), pn, n * 4 * sizeof(N));
+    std::memcpy(s.latticeC.data(), c, n * 4 * sizeof(N));
+    return s.mc_emit(*p, *m, n_triangles);
+  });
+}
+int pbf_oracle_get_lattice(const pbf_oracle *o, uint64_t sample[3], void *pn, void *c) {
+  return dispatch(o, [&](const auto &s) {
+    for (int k = 0; k < 3; ++k) sample[k] = s.sample[k];
+    if (pn) std::memcpy(pn, s.latticePN.data(), s.latticePN.size() * sizeof(s.latticePN[0]));
+    if (c) std::memcpy(c, s.latticeC.data(), s.latticeC.size() * sizeof(s.latticeC[0]));
+    return 0;
+  });
+}
+int pbf_oracle_get_mesh(const pbf_oracle *o, void *vs, void *ns, void *cs) {
+  return dispatch(o, [&](const auto &s) {
+    if (vs) std::memcpy(vs, s.meshV.data(), s.meshV.size() * sizeof(s.meshV[0]));
+    if (ns) std::memcpy(ns, s.meshN.data(), s.meshN.size() * sizeof(s.meshN[0]));
+    if (cs) std::memcpy(cs, s.meshC.data(), s.meshC.size() * sizeof(s.meshC[0]));
+    return 0;
+  });
 }
 
 int pbf_oracle_set_scratch(pbf_oracle *o, const uint64_t *keys, const void *pstar, const void *lambda) {

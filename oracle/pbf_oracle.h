@@ -108,6 +108,19 @@ size_t pbf_oracle_scene_dambreak(int fp64, size_t nominal, uint64_t *id, void *m
 /* applyMotionSinXCosZ (sph.hpp:147-158): offset added to min/max bound at a frame, computed in float */
 void pbf_oracle_motion_offset(int fp64, uint64_t frame, double out[3]);
 
+/* Marching-cubes surface of the CURRENT state (ompsph.hpp:277-477; run after pbf_oracle_step, which leaves
+ * the sorted particles, their predict-time cells and the grid table in place).  McParams = sph.hpp:82-95.
+ * Mesh: 3 vertices per triangle, in cube order. */
+typedef struct pbf_oracle_mc {
+  double resolution, isolevel, particle_size, particle_influence;
+} pbf_oracle_mc;
+int pbf_oracle_surface(pbf_oracle *, const pbf_oracle_params *, const pbf_oracle_mc *, uint64_t *n_triangles);
+/* emit stage only, from a given lattice (sample[0]*sample[1]*sample[2] nodes, 4 + 4 values each) */
+int pbf_oracle_surface_from_lattice(pbf_oracle *, const pbf_oracle_params *, const pbf_oracle_mc *,
+                                    const uint64_t sample[3], const void *pn, const void *c, uint64_t *n_triangles);
+int pbf_oracle_get_lattice(const pbf_oracle *, uint64_t sample[3], void *pn, void *c);
+int pbf_oracle_get_mesh(const pbf_oracle *, void *vs /* 9n */, void *ns /* 9n */, void *cs /* 12n */);
+
 /* Overwrite the scratch state (same order as the particles); NULL = leave.  Used by the tests of the
  * slab driver, which re-assemble owned particles + ghost copies (type bit 1 = ghost: a candidate that is
  * never updated locally) between stages. */

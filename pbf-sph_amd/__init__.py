@@ -14,6 +14,7 @@ from .capi import (  # noqa: F401
     FLAG_NO_LDS,
     FLAG_STAGE_TIMING,
     LIB_PATH,
+    McParams,
     Params,
     PbfError,
     SlabCut,

@@ -63,6 +63,15 @@ class Params(C.Structure):
         return self
 
 
+class McParams(C.Structure):
+    """sph::McParams (sph.hpp:82-95); defaults = simpleConfigWith2Cubes' (sph.hpp:179-184)."""
+    _fields_ = [("resolution", C.c_double), ("isolevel", C.c_double), ("particle_size", C.c_double),
+                ("particle_influence", C.c_double)]
+
+    def __init__(self, resolution=2.0, isolevel=100.0, particle_size=25.0, particle_influence=0.5):
+        super().__init__(resolution, isolevel, particle_size, particle_influence)
+
+
 class SlabCut(C.Structure):
     _fields_ = [("xlo", C.c_uint32), ("xhi", C.c_uint32), ("has_left", C.c_int32), ("has_right", C.c_int32)]
 
@@ -109,6 +118,9 @@ _SIGS = {
     "pbf_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                   C.c_int]),
     "pbf_reset_stage_times": (C.c_int, [C.c_void_p]),
+    "pbf_surface": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(C.c_uint64)]),
+    "pbf_download_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pbf_read_lattice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pbf_reserve": (C.c_int, [C.c_void_p, C.c_size_t]),
     "pbf_slab_configure": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "pbf_slab_record_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
@@ -280,6 +292,21 @@ class Solver:
         a = np.empty((self.n, 4), self.dtype)
         self._chk(self.L.pbf_read_buffer(self.ctx, BUF_PSTAR, _vp(a), a.nbytes), "read pstar")
         return a
+
+    def surface(self, p, mc=None):
+        """Marching cubes on the state the last step left -> dict(vs, ns, cs, sample, pn, c)."""
+        mc = mc or McParams()
+        nt = C.c_uint64()
+        self._chk(self.L.pbf_surface(self.ctx, C.byref(p), C.byref(mc), C.byref(nt)), "pbf_surface")
+        n = nt.value
+        vs, ns, cs = np.empty((3 * n, 3), self.dtype), np.empty((3 * n, 3), self.dtype), np.empty((3 * n, 4), self.dtype)
+        self._chk(self.L.pbf_download_mesh(self.ctx, _vp(vs), _vp(ns), _vp(cs)), "pbf_download_mesh")
+        smp = np.zeros(3, np.uint64)
+        self._chk(self.L.pbf_read_lattice(self.ctx, _vp(smp), None, None), "pbf_read_lattice")
+        nn = int(smp.prod())
+        pn, cc = np.empty((nn, 4), self.dtype), np.empty((nn, 4), self.dtype)
+        self._chk(self.L.pbf_read_lattice(self.ctx, _vp(smp), _vp(pn), _vp(cc)), "pbf_read_lattice")
+        return dict(vs=vs, ns=ns, cs=cs, sample=smp, pn=pn, c=cc)
 
     def extent(self):
         e = np.zeros(3, np.uint64)

@@ -16,6 +16,7 @@
 
 #include "pbf_kernels.hpp"
 #include "pbf_slab.hpp"
+#include "pbf_mc.hpp"
 
 using namespace pbf;
 
@@ -73,6 +74,10 @@ struct pbf_ctx {
   int32_t shiftL = 0, shiftR = 0;
   size_t reserve = 0;        // pbf_reserve: capacity kept for migrants and ghost copies
   uint32_t nOwned = 0, sentL = 0, sentR = 0, gotL = 0, gotR = 0;
+  // marching cubes (pbf_surface)
+  DevBuf latticePN, latticeC, mcCounts, mcOffsets, mcSums, meshV, meshN, meshC;
+  uint64_t mcSample[3] = {0, 0, 0};
+  uint64_t mcTriangles = 0;
   DevBuf nbrList, nbrCount;  // neighbour lists handed from the lambda launch to the delta launch (NBR_CAP per particle)
   bool nbrValid = false;     // the lists describe pstar[pcur] as it is now
   bool reuseLists = true;    // option "reuse_lists"
@@ -746,7 +751,8 @@ void pbf_destroy(pbf_ctx *ctx) {
                    &ctx->id[0],   &ctx->id[1],   &ctx->type[0], &ctx->type[1], &ctx->key[0],   &ctx->key[1],
                    &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2], &ctx->count, &ctx->table,   &ctx->blockSums,
                    &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl,
-                   &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR};
+                   &ctx->latticePN, &ctx->latticeC, &ctx->mcCounts, &ctx->mcOffsets, &ctx->mcSums, &ctx->meshV, &ctx->meshN,
+                   &ctx->meshC, &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR};
   for (DevBuf *b : all)
     if (b->p) (void)hipFree(b->p);
   if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
@@ -1137,5 +1143,107 @@ int pbf_slab_finish(pbf_ctx *ctx) {
   return DISPATCH(ctx, slab_finish, ctx);
 }
 size_t pbf_owned_count(const pbf_ctx *ctx) { return ctx ? (ctx->slabActive ? ctx->nOwned : ctx->n) : 0; }
+
+}  // extern "C"
+
+// ================================================================================================
+// Marching-cubes surface (pbf_surface / pbf_download_mesh): reference src/omp/ompsph.hpp:277-477
+// ================================================================================================
+namespace {
+
+template <typename N> int surface_impl(pbf_ctx *ctx, const pbf_params *p, const pbf_mc_params *mp, uint64_t *nTriangles) {
+  StepConsts<N> c;
+  if (int rc = make_consts<N>(ctx, p, c)) return rc;
+  if (ctx->slabConfigured) return fail(ctx, PBF_ERR_INVALID, "pbf_surface is not available in slab mode yet");
+  McConsts<N> m;
+  m.scale = c.scale, m.res = N(mp->resolution), m.isolevel = N(mp->isolevel), m.particleSize = N(mp->particle_size);
+  m.particleInfluence = N(mp->particle_influence);
+  m.step = c.h / m.res;           // ompsph.hpp:291
+  m.threshold = c.h * c.scale * 1;  // ompsph.hpp:293
+  uint64_t latticeN = 1;
+  for (int k = 0; k < 3; ++k) {
+    m.minExtent[k] = c.minExtent[k];
+    m.extent[k] = uint32_t(ctx->extent[k]);
+    const uint64_t smp = uint64_t(std::floor(N(ctx->extent[k]) * m.res)) + 1;  // ompsph.hpp:283-284
+    m.sample[k] = uint32_t(smp);
+    ctx->mcSample[k] = smp;
+    latticeN *= smp;
+  }
+  if (latticeN >= (uint64_t(1) << 31)) return fail(ctx, PBF_ERR_INVALID, "surface lattice too large (resolution x extent)");
+  m.tableN = c.tableN, m.hasObstacles = c.hasObstacles;
+  const int s = ctx->cur;
+  if (int rc = ensure(ctx, ctx->latticePN, latticeN * sizeof(vec4<N>))) return rc;
+  if (int rc = ensure(ctx, ctx->latticeC, latticeN * sizeof(vec4<N>))) return rc;
+  hipLaunchKernelGGL((k_mc_field<N>), grid_for(latticeN), dim3(BLOCK), 0, ctx->stream, m, ctx->table.as<const uint32_t>(),
+                     ctx->pos4[s].as<const vec4<N>>(), ctx->col4[s].as<const vec4<N>>(), ctx->type[s].as<const uint8_t>(),
+                     ctx->latticePN.as<vec4<N>>(), ctx->latticeC.as<vec4<N>>());
+  LAUNCH_CHECK(ctx);
+  *nTriangles = 0;
+  ctx->mcTriangles = 0;
+  if (m.sample[0] < 2 || m.sample[1] < 2 || m.sample[2] < 2) return PBF_OK;
+  const uint64_t march64 = uint64_t(m.sample[0] - 1) * (m.sample[1] - 1) * (m.sample[2] - 1);
+  const uint32_t marchVolume = uint32_t(march64), len = marchVolume + 1;
+  const uint32_t nb = (len + SCAN_TILE - 1) / SCAN_TILE;
+  if (int rc = ensure(ctx, ctx->mcCounts, (size_t(len) + SCAN_TILE) * 4)) return rc;
+  if (int rc = ensure(ctx, ctx->mcOffsets, (size_t(len) + SCAN_TILE) * 4)) return rc;
+  if (int rc = ensure(ctx, ctx->mcSums, (size_t(nb) + 1) * 4)) return rc;
+  uint32_t *counts = ctx->mcCounts.as<uint32_t>(), *offsets = ctx->mcOffsets.as<uint32_t>(), *sums = ctx->mcSums.as<uint32_t>();
+  HIPCHK(ctx, hipMemsetAsync(counts + marchVolume, 0, 4, ctx->stream));  // closing sentinel: offsets[marchVolume] = total
+  hipLaunchKernelGGL((k_mc_count<N>), grid_for(marchVolume), dim3(BLOCK), 0, ctx->stream, m, marchVolume,
+                     ctx->latticePN.as<const vec4<N>>(), counts);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(BLOCK), 0, ctx->stream, counts, len, sums);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLOCK), 0, ctx->stream, sums, nb);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(BLOCK), 0, ctx->stream, counts, len, sums, offsets);
+  LAUNCH_CHECK(ctx);
+  uint32_t total = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&total, offsets + marchVolume, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the mesh buffers are sized from the count
+  ctx->mcTriangles = total;
+  *nTriangles = total;
+  if (total == 0) return PBF_OK;
+  if (int rc = ensure(ctx, ctx->meshV, size_t(total) * 9 * sizeof(N))) return rc;
+  if (int rc = ensure(ctx, ctx->meshN, size_t(total) * 9 * sizeof(N))) return rc;
+  if (int rc = ensure(ctx, ctx->meshC, size_t(total) * 12 * sizeof(N))) return rc;
+  hipLaunchKernelGGL((k_mc_emit<N>), grid_for(marchVolume), dim3(BLOCK), 0, ctx->stream, m, marchVolume,
+                     ctx->latticePN.as<const vec4<N>>(), ctx->latticeC.as<const vec4<N>>(), offsets, ctx->meshV.as<N>(),
+                     ctx->meshN.as<N>(), ctx->meshC.as<N>());
+  LAUNCH_CHECK(ctx);
+  return PBF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pbf_surface(pbf_ctx *ctx, const pbf_params *params, const pbf_mc_params *mc, uint64_t *n_triangles) {
+  if (int rc = check(ctx, params, true)) return rc;
+  if (!mc || !n_triangles) return fail(ctx, PBF_ERR_INVALID, "NULL argument");
+  if (!(mc->resolution > 0)) return fail(ctx, PBF_ERR_INVALID, "resolution must be > 0");
+  return DISPATCH(ctx, surface_impl, ctx, params, mc, n_triangles);
+}
+
+int pbf_download_mesh(pbf_ctx *ctx, void *vs, void *ns, void *cs) {
+  if (!ctx) return PBF_ERR_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = ctx->mcTriangles, e = ctx->fp64 ? 8 : 4;
+  if (n == 0) return PBF_OK;
+  if (vs) HIPCHK(ctx, hipMemcpyAsync(vs, ctx->meshV.p, n * 9 * e, hipMemcpyDeviceToHost, ctx->stream));
+  if (ns) HIPCHK(ctx, hipMemcpyAsync(ns, ctx->meshN.p, n * 9 * e, hipMemcpyDeviceToHost, ctx->stream));
+  if (cs) HIPCHK(ctx, hipMemcpyAsync(cs, ctx->meshC.p, n * 12 * e, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PBF_OK;
+}
+
+int pbf_read_lattice(pbf_ctx *ctx, uint64_t sample[3], void *pn, void *c) {
+  if (!ctx || !sample) return PBF_ERR_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  size_t n = 1;
+  for (int k = 0; k < 3; ++k) sample[k] = ctx->mcSample[k], n *= ctx->mcSample[k];
+  const size_t v = ctx->fp64 ? sizeof(double4) : sizeof(float4);
+  if (n && pn) HIPCHK(ctx, hipMemcpyAsync(pn, ctx->latticePN.p, n * v, hipMemcpyDeviceToHost, ctx->stream));
+  if (n && c) HIPCHK(ctx, hipMemcpyAsync(c, ctx->latticeC.p, n * v, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PBF_OK;
+}
 
 }  // extern "C"

@@ -1,0 +1,154 @@
+// pbf_mc.hpp — marching-cubes surface extraction on the device (reference: src/omp/ompsph.hpp:277-477,
+// OpenCL kernels mc_lattice / mc_size / mc_eval in src/ocl/oclsph_kernel.h:176-408).
+//   k_mc_field : one lane per lattice node — 27-cell gather (cells clamped to the grid, so they may
+//                repeat at the domain faces exactly like the reference) of  v = sum size / |l|^infl,
+//                the un-normalised gradient and the mean colour of the particles within h*scale;
+//   k_mc_count : one lane per cube — case index from the 8 corner values, triangles of that case;
+//                an exclusive scan of the counts (the grid-table scan kernels) gives every cube its
+//                output offset, so triangles come out in cube order, deterministically (the
+//                reference appends through an atomic counter, i.e. in arbitrary order);
+//   k_mc_emit  : one lane per cube — edge intersections by linear interpolation, triangles from the
+//                case table.
+// Case tables: mc_tables.hpp, generated from first principles by tools/gen_mc_tables.py (the
+// reference's src/mc_constants.h is data we may not copy): same corner / edge numbering, our own
+// polygon triangulation — the surface is the same, the triangle count per case need not be.
+// glm's fastDistance / fastLength / fastNormalize (approximations without a bit contract, library
+// absent offline) are evaluated with the exact sqrt, like the oracle.
+#pragma once
+
+#include "mc_tables.hpp"
+#include "pbf_kernels.hpp"
+
+namespace pbf {
+
+template <typename N> struct McConsts {
+  N scale, res, isolevel, particleSize, particleInfluence, step, threshold;
+  N minExtent[3];
+  uint32_t extent[3];
+  uint32_t sample[3];
+  uint32_t tableN;
+  uint32_t hasObstacles;
+};
+
+template <typename N>
+__global__ __launch_bounds__(BLOCK) void k_mc_field(McConsts<N> m, const uint32_t *__restrict__ table,
+                                                    const vec4<N> *__restrict__ pos4,
+                                                    const vec4<N> *__restrict__ col4,
+                                                    const uint8_t *__restrict__ type, vec4<N> *__restrict__ latticePN,
+                                                    vec4<N> *__restrict__ latticeC) {
+  const uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+  const uint32_t sy = m.sample[1], sz = m.sample[2];
+  if (idx >= m.sample[0] * sy * sz) return;
+  const uint32_t x = idx / (sy * sz), y = (idx / sz) % sy, z = idx % sz;  // index3d (curves.h:17-19)
+  const N px = N(x), py = N(y), pz = N(z);
+  const N ax = (m.minExtent[0] + (px * m.step)) * m.scale, ay = (m.minExtent[1] + (py * m.step)) * m.scale,
+          az = (m.minExtent[2] + (pz * m.step)) * m.scale;
+  // the node's cell (ompsph.hpp:293-298); coordinates pass through the 10-bit Morton encode / decode
+  const uint32_t zX = uint32_t(uint64_t(px / m.res)) & 1023u, zY = uint32_t(uint64_t(py / m.res)) & 1023u,
+                 zZ = uint32_t(uint64_t(pz / m.res)) & 1023u;
+  const vec4<N> zero = make_vec4<N>(N(0), N(0), N(0), N(0));
+  if (zX == m.extent[0] && zY == m.extent[1] && zZ == m.extent[2]) {  // ompsph.hpp:300-303
+    latticePN[idx] = zero, latticeC[idx] = zero;
+    return;
+  }
+  auto cl = [](int v, int hi) { return uint32_t(min(max(v, 0), hi)); };
+  const uint32_t xs[3] = {cl(int(zX) - 1, int(m.extent[0]) - 1), zX, cl(int(zX) + 1, int(m.extent[0]) - 1)};
+  const uint32_t ys[3] = {cl(int(zY) - 1, int(m.extent[1]) - 1), zY, cl(int(zY) + 1, int(m.extent[1]) - 1)};
+  const uint32_t zs[3] = {cl(int(zZ) - 1, int(m.extent[2]) - 1), zZ, cl(int(zZ) + 1, int(m.extent[2]) - 1)};
+  N v = 0, nx = 0, ny = 0, nz = 0, cr = 0, cg = 0, cb = 0, ca = 0;
+  uint32_t nNeighbours = 0;
+  const N ninf = (-m.particleInfluence) * m.particleSize;
+#pragma unroll 1
+  for (int dz = 0; dz < 3; ++dz)
+#pragma unroll 1
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll 1
+      for (int dx = 0; dx < 3; ++dx) {
+        const uint32_t off = morton_encode(xs[dx], ys[dy], zs[dz]);
+        if (off >= m.tableN) continue;
+        const uint32_t s0 = table[off], e0 = (off + 1u) < m.tableN ? table[off + 1u] : s0;
+        for (uint32_t b = s0; b < e0; ++b) {
+          if (m.hasObstacles && type[b] != 0) continue;
+          const vec4<N> p = pos4[b];
+          const N lx = p.x - ax, ly = p.y - ay, lz = p.z - az;
+          const N len = sqrt(lx * lx + ly * ly + lz * lz);
+          if (!(len < m.threshold)) continue;
+          const N denominator = pow(len, m.particleInfluence);
+          v += (m.particleSize / denominator);
+          nx = nx + (lx / denominator) * ninf, ny = ny + (ly / denominator) * ninf, nz = nz + (lz / denominator) * ninf;
+          const vec4<N> c = col4[b];
+          cr += c.x, cg += c.y, cb += c.z, ca += c.w;
+          nNeighbours++;
+        }
+      }
+  const N inv = N(1) / sqrt(nx * nx + ny * ny + nz * nz);
+  latticePN[idx] = make_vec4<N>(v, nx * inv, ny * inv, nz * inv);
+  const N nn = N(nNeighbours);
+  latticeC[idx] = make_vec4<N>(cr / nn, cg / nn, cb / nn, ca / nn);
+}
+
+__device__ inline void mc_cube_origin(uint32_t i, const uint32_t sample[3], uint32_t &px, uint32_t &py, uint32_t &pz) {
+  const uint32_t ry = sample[1] - 1u, rz = sample[2] - 1u;  // utils::to3d over the march range
+  px = i / (ry * rz), py = (i / rz) % ry, pz = i % rz;
+}
+
+template <typename N>
+__device__ inline uint32_t mc_case(const McConsts<N> &m, const vec4<N> *__restrict__ latticePN, uint32_t px, uint32_t py,
+                                   uint32_t pz, N values[8], uint32_t node[8]) {
+  const uint32_t CX[8] = {0, 1, 1, 0, 0, 1, 1, 0}, CY[8] = {0, 0, 1, 1, 0, 0, 1, 1}, CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  uint32_t ci = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {  // CUBE_OFFSETS (ompsph.hpp:356-358)
+    node[k] = ((px + CX[k]) * m.sample[1] + (py + CY[k])) * m.sample[2] + (pz + CZ[k]);
+    values[k] = latticePN[node[k]].x;
+    if (values[k] < m.isolevel) ci |= 1u << k;
+  }
+  return ci;
+}
+
+template <typename N>
+__global__ __launch_bounds__(BLOCK) void k_mc_count(McConsts<N> m, uint32_t marchVolume,
+                                                    const vec4<N> *__restrict__ latticePN,
+                                                    uint32_t *__restrict__ counts) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= marchVolume) return;
+  uint32_t px, py, pz, node[8];
+  N values[8];
+  mc_cube_origin(i, m.sample, px, py, pz);
+  const uint32_t ci = mc_case<N>(m, latticePN, px, py, pz, values, node);
+  counts[i] = kMcEdgeTable[ci] == 0 ? 0u : uint32_t(kMcNumVerts[ci]) / 3u;  // ompsph.hpp:377
+}
+
+template <typename N>
+__global__ __launch_bounds__(BLOCK) void k_mc_emit(McConsts<N> m, uint32_t marchVolume,
+                                                   const vec4<N> *__restrict__ latticePN,
+                                                   const vec4<N> *__restrict__ latticeC,
+                                                   const uint32_t *__restrict__ offsets, N *__restrict__ outV,
+                                                   N *__restrict__ outN, N *__restrict__ outC) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= marchVolume) return;
+  if (offsets[i + 1] == offsets[i]) return;
+  uint32_t px, py, pz, node[8];
+  N values[8];
+  mc_cube_origin(i, m.sample, px, py, pz);
+  const uint32_t ci = mc_case<N>(m, latticePN, px, py, pz, values, node);
+  const uint32_t CX[8] = {0, 1, 1, 0, 0, 1, 1, 0}, CY[8] = {0, 0, 1, 1, 0, 0, 1, 1}, CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  const int EF[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, ET[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};  // lerpAll pairs
+  uint32_t w = offsets[i] * 3u;
+  for (int k = 0; kMcTriTable[ci][k] != 255; ++k, ++w) {
+    const int e = kMcTriTable[ci][k];
+    const int f = EF[e], t = ET[e];
+    const N wgt = (m.isolevel - values[f]) / (values[t] - values[f]);  // utils::scale (utils.hpp:85)
+    auto mix = [&](N a, N b) { return a * (N(1) - wgt) + b * wgt; };   // glm::mix
+    auto coord = [&](uint32_t c, int ax) { return (m.minExtent[ax] + (N(c) * m.step)) * m.scale; };
+    const vec4<N> pf = latticePN[node[f]], pt = latticePN[node[t]], cf = latticeC[node[f]], ct = latticeC[node[t]];
+    outV[3 * w + 0] = mix(coord(px + CX[f], 0), coord(px + CX[t], 0));
+    outV[3 * w + 1] = mix(coord(py + CY[f], 1), coord(py + CY[t], 1));
+    outV[3 * w + 2] = mix(coord(pz + CZ[f], 2), coord(pz + CZ[t], 2));
+    outN[3 * w + 0] = mix(pf.y, pt.y), outN[3 * w + 1] = mix(pf.z, pt.z), outN[3 * w + 2] = mix(pf.w, pt.w);
+    outC[4 * w + 0] = mix(cf.x, ct.x), outC[4 * w + 1] = mix(cf.y, ct.y), outC[4 * w + 2] = mix(cf.z, ct.z),
+                 outC[4 * w + 3] = mix(cf.w, ct.w);
+  }
+}
+
+}  // namespace pbf

@@ -27,6 +27,7 @@ struct Args {
   size_t solverIter = 6;                  // --solver-iter (stock: benchmark.cpp:24)
   std::string scene = "cubes";            // --scene cubes|dam-break
   bool resident = false;                  // --resident: keep particles on the GPU between frames
+  bool surface = true;                    // --no-surface: skip marching cubes (stock: on, benchmark.cpp:29)
   bool fastMath = false;                  // --fast-math
   bool json = false;                      // --json: one machine-readable line after the summary
 
@@ -57,6 +58,7 @@ struct Args {
           "      --solver-iter=[k]                 Solver iterations per frame. Default: 6 (stock)\n"
           "      --scene=[cubes|dam-break]         cubes = stock two cubes in a moving box; dam-break = static box\n"
           "      --resident                        Time the device-resident loop (no per-frame host round trip)\n"
+          "      --no-surface                      Skip the marching-cubes surface (the stock driver runs with it on)\n"
           "      --fast-math                       v_rsq / fma pair kernels (the reference builds with -Ofast)\n"
           "      --json                            Print one JSON line with the results\n";
   }
@@ -91,6 +93,7 @@ struct Args {
         else if (a == "-v" || a == "--verbose") verbose = true;
         else if (a == "--fp64") fp64 = true;
         else if (a == "--resident") resident = true;
+        else if (a == "--no-surface") surface = false;
         else if (a == "--fast-math") fastMath = true;
         else if (a == "--json") json = true;
         else if (value(i, a, "-i", "--impl", v)) impl = v;

@@ -4,9 +4,10 @@
 // then `iter` timed ones, each with applyMotionSinXCosZ(param, frame) and an empty Scene
 // (benchmark.cpp:22-58); then the summary block of benchmark.cpp:91-101 and "Results flushed.".
 // Stock defaults: 20000 nominal particles (2 x 21^3 = 18522), 6 solver iterations, scale 500, h = 0.1
-// (benchmark.cpp:23-25,160-163).  Differences, all visible in the output: the only backend is `hip`;
-// marching-cubes surface extraction is not built yet, so "Final Vertex count" is 0; extra lines
-// report particle-steps/s; --resident times the device-resident loop.
+// (benchmark.cpp:23-25,160-163), marching-cubes surface on (benchmark.cpp:29; --no-surface turns it off).
+// Differences, all visible in the output: the only backend is `hip`; extra lines report particle-steps/s;
+// --resident times the device-resident loop; the surface's case tables are our own, so the vertex
+// count need not equal the reference's triangle for triangle.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -88,8 +89,9 @@ template <typename N> int run(const sph::driver::Args &args, int device) {
   } else {
     std::tie(param, particles) = sph::damBreakConfig<T, N, sph::vec>(args.particles, args.solverIter, N(500));
   }
-  // the stock driver sets param.surface = initialMcParam (benchmark.cpp:29); surface extraction is not built here
-  param.surface = {};
+  // the stock driver runs with the surface on: param.surface = initialMcParam (benchmark.cpp:29)
+  if (!moving) mc = sph::McParams<N>{N(2.0f), N(100), N(25), N(0.5)};  // the same McParams for the dam-break scene
+  if (args.surface) param.surface = mc;
 
   uint32_t flags = (args.fastMath ? PBF_FLAG_FAST_MATH : 0u) | (args.verbose ? PBF_FLAG_STAGE_TIMING : 0u);
   sph::hip_impl::Solver<T, N> solver(N(0.1), device, flags);
@@ -102,6 +104,7 @@ template <typename N> int run(const sph::driver::Args &args, int device) {
   auto one = [&](size_t frame) {
     if (args.resident) {
       solver.step(frameParam(frame));
+      if (param.surface) result.mesh = solver.surface(frameParam(frame));
       solver.sync();  // per-frame time like the reference's blocking advance()
     } else {
       result = solver.advance(frameParam(frame), {}, particles);

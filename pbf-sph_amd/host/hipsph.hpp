@@ -10,8 +10,8 @@
 //   upload()/step()/download()   the device-resident fast path the benchmark times as well.
 //
 // Host-side scene handling restates the observable behaviour of ompsph.hpp:91-126 (sources emit,
-// drains erase, empty -> "Particles depleted") and :167-186 (queries).  Marching-cubes surface
-// extraction (config.surface) is not built yet: the mesh comes back empty.
+// drains erase, empty -> "Particles depleted") and :167-186 (queries).  config.surface runs the
+// marching-cubes kernels (pbf_surface) and fills Result::mesh like ompsph.hpp:277-477.
 #pragma once
 
 #include <algorithm>
@@ -136,8 +136,21 @@ public:
     step(config, scene, 1);
     sph::Result<T, N, V> result;
     if (!scene.queries.empty()) result.queries = query(config, scene);
+    if (config.surface) result.mesh = surface(config, scene);  // ompsph.hpp:277-477
     download(xs);
     return result;
+  }
+
+  // Marching-cubes surface of the state the last step left (reference: config.surface, ompsph.hpp:277-477).
+  sph::ColouredMesh<N, V> surface(const sph::SphParams<T, N, V> &config, const sph::Scene<T, N, V> &scene = {}) {
+    const pbf_params p = params(config, scene);
+    const pbf_mc_params mc{double(config.surface->resolution), double(config.surface->isolevel),
+                           double(config.surface->particleSize), double(config.surface->particleInfluence)};
+    uint64_t triangles = 0;
+    check(pbf_surface(ctx_, &p, &mc, &triangles), "pbf_surface");
+    sph::ColouredMesh<N, V> mesh(size_t(triangles) * 3);
+    check(pbf_download_mesh(ctx_, mesh.vs.data(), mesh.ns.data(), mesh.cs.data()), "pbf_download_mesh");
+    return mesh;
   }
 
 private:

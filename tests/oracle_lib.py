@@ -18,6 +18,15 @@ GS, JACOBI = 0, 1
 SORT_STD, SORT_STABLE = 0, 1
 
 
+class OracleMc(C.Structure):
+    """sph::McParams (sph.hpp:82-95); defaults = simpleConfigWith2Cubes' (sph.hpp:179-184)."""
+    _fields_ = [("resolution", C.c_double), ("isolevel", C.c_double), ("particle_size", C.c_double),
+                ("particle_influence", C.c_double)]
+
+    def __init__(self, resolution=2.0, isolevel=100.0, particle_size=25.0, particle_influence=0.5):
+        super().__init__(resolution, isolevel, particle_size, particle_influence)
+
+
 class OracleParams(C.Structure):
     _fields_ = [
         ("h", C.c_double),
@@ -92,6 +101,11 @@ def lib():
         L.pbf_oracle_motion_offset.argtypes = [C.c_int, C.c_uint64, C.c_void_p]
         L.pbf_oracle_set_pow4.argtypes = [C.c_void_p, C.c_int]
         L.pbf_oracle_set_scratch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pbf_oracle_surface.argtypes = [C.c_void_p, C.POINTER(OracleParams), C.POINTER(OracleMc), C.POINTER(C.c_uint64)]
+        L.pbf_oracle_surface_from_lattice.argtypes = [C.c_void_p, C.POINTER(OracleParams), C.POINTER(OracleMc), C.c_void_p,
+                                                      C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.pbf_oracle_get_lattice.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pbf_oracle_get_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -243,6 +257,28 @@ class Oracle:
         ps = None if pstar is None else np.ascontiguousarray(pstar, self.dtype)
         la = None if lambdas is None else np.ascontiguousarray(lambdas, self.dtype)
         self.L.pbf_oracle_set_scratch(self.h, _vp(k), _vp(ps), _vp(la))
+
+    def surface(self, p, mc=None, lattice=None):
+        """Marching cubes on the current state -> dict(vs, ns, cs, sample, pn, c).  lattice=(sample, pn, c) runs
+        the emit stage only on a given lattice."""
+        mc = mc or OracleMc()
+        nt = C.c_uint64()
+        if lattice is None:
+            self.L.pbf_oracle_surface(self.h, C.byref(p), C.byref(mc), C.byref(nt))
+        else:
+            smp = np.ascontiguousarray(lattice[0], np.uint64)
+            pn = np.ascontiguousarray(lattice[1], self.dtype)
+            cc = np.ascontiguousarray(lattice[2], self.dtype)
+            self.L.pbf_oracle_surface_from_lattice(self.h, C.byref(p), C.byref(mc), _vp(smp), _vp(pn), _vp(cc), C.byref(nt))
+        n = nt.value
+        vs, ns, cs = np.empty((3 * n, 3), self.dtype), np.empty((3 * n, 3), self.dtype), np.empty((3 * n, 4), self.dtype)
+        self.L.pbf_oracle_get_mesh(self.h, _vp(vs), _vp(ns), _vp(cs))
+        smp = np.zeros(3, np.uint64)
+        self.L.pbf_oracle_get_lattice(self.h, _vp(smp), None, None)
+        nn = int(smp.prod())
+        pn, cc = np.empty((nn, 4), self.dtype), np.empty((nn, 4), self.dtype)
+        self.L.pbf_oracle_get_lattice(self.h, _vp(smp), _vp(pn), _vp(cc))
+        return dict(vs=vs, ns=ns, cs=cs, sample=smp, pn=pn, c=cc)
 
     def table(self):
         t = np.empty(self.L.pbf_oracle_table_size(self.h), np.uint64)
