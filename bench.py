@@ -124,14 +124,18 @@ def main():
         # Weak scaling: `world` dam-break columns side by side along x, one per rank, in ONE box of
         # world*side x side x side; slabs of equal width, ghost-layer exchange over RCCL (slab.py).
         from pbf_sph_amd import slab
-        scene["pos"][:, 0] += type(scene["pos"][0, 0])(rank * side)
+        # Odd ranks hold the MIRROR image of the column (x -> side - x inside their sub-box): every cut plane is
+        # then a mirror plane of the whole set-up, i.e. dynamically a wall — each rank's problem is the N = 1
+        # dam-break, the net flux through a cut is zero and the load stays balanced (up to chaotic symmetry breaking).
+        x = scene["pos"][:, 0]
+        scene["pos"][:, 0] = (x.dtype.type(side) - x if rank % 2 else x) + x.dtype.type(rank * side)
         scene["id"] += np.uint64(rank * n)
         p.max_bound[0] = world * side
         stream = torch.cuda.Stream()
         torch.cuda.set_stream(stream)  # RCCL ops and the solver's kernels are ordered on this one stream
         solver = pkg.Solver(h=0.1, fp64=args.fp64, device=local_rank, flags=flags, stream=stream.cuda_stream)
-        cap = max(n // 2, 1 << 16)
-        solver._chk(solver.L.pbf_reserve(solver.ctx, n + 2 * cap), "pbf_reserve")
+        cap = max(n // 2, 1 << 16)  # wire records per neighbour and phase
+        solver._chk(solver.L.pbf_reserve(solver.ctx, 3 * n + 2 * cap), "pbf_reserve")  # head-room if the load drifts
         solver.upload(**scene)
         eng = slab.HipEngine(solver, torch, torch.device("cuda", local_rank))
         drv = slab.SlabSolver(eng, dist, rank, world, slab.even_cuts(world, world * side), cap,
@@ -214,7 +218,7 @@ def main():
                        "math": "fast (v_rsq, fma)" if args.fast_math else "precise (IEEE div/sqrt, no contraction)",
                        "parallelism": "1 GPU, device-resident" if world == 1 else
                                       f"{world} x-slabs, one rank per GPU, 1-cell ghost layer refreshed after every "
-                                      f"lambda/delta launch over RCCL ({backend}); box {world}x1x1 columns; "
+                                      f"lambda/delta launch over RCCL ({backend}); {world} columns side by side, odd ones mirrored; "
                                       f"max rank load {imbalance:.2f}x mean"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
