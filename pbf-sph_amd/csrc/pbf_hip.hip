@@ -78,9 +78,11 @@ struct pbf_ctx {
   DevBuf latticePN, latticeC, mcCounts, mcOffsets, mcSums, meshV, meshN, meshC;
   uint64_t mcSample[3] = {0, 0, 0};
   uint64_t mcTriangles = 0;
+  DevBuf qpos;               // 8-byte quantised pStar for the list build (k_build_lists_q)
   DevBuf nbrList, nbrCount;  // neighbour lists handed from the lambda launch to the delta launch (NBR_CAP per particle)
   bool nbrValid = false;     // the lists describe pstar[pcur] as it is now
   bool reuseLists = true;    // option "reuse_lists"
+  int splitBuild = 0;   // option "split_build": list build and lambda as two launches
   bool fuseDiffuse = false;  // option "fuse_diffuse": pbf_step folds the diffuse walk into the first lambda launch
                              // (bit-identical; measured 2 % SLOWER at 1 M — the colour loads stall the filter loop — so off)
   bool fuseDiffuseNow = false;
@@ -154,6 +156,7 @@ int ensure_particles(pbf_ctx *ctx, size_t n) {
     if (int rc = ensure(ctx, ctx->pstar[s], n * v)) return rc;
   if (int rc = ensure(ctx, ctx->permTmp, n * 4)) return rc;
   if (int rc = ensure(ctx, ctx->slotOf, n * 4)) return rc;
+  if (int rc = ensure(ctx, ctx->qpos, n * 8 + 16)) return rc;
   if (int rc = ensure(ctx, ctx->nbrCount, n * 4)) return rc;
   if (int rc = ensure(ctx, ctx->nbrList, ((n + BLOCK - 1) / BLOCK) * size_t(NBR_CAP) * BLOCK * 4)) return rc;
   ctx->cap = n;
@@ -403,6 +406,25 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
     uint32_t *nl = ctx->nbrList.as<uint32_t>(), *nc = ctx->nbrCount.as<uint32_t>();
     const dim3 g = grid_for(ctx->n), b(BLOCK);
     if (mode == GATHER_FROM_LISTS) {
+      hipLaunchKernelGGL((k_gather_from_lists<N, Op>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
+    } else if (mode == GATHER_SAVE_LISTS && ctx->splitBuild &&
+               uint64_t(ctx->n) * sizeof(typename Op::Src) <= 0xFFFFFFFFull) {  // (k_build_lists: 32-bit offsets)  // build the lists, then run the op list-driven
+      if (ctx->splitBuild == 1)
+        hipLaunchKernelGGL((k_gather_lists<N, Op, 16, true, NoExtra, true>), g, b, 0, ctx->stream, c, args, key, table,
+                           nl, nc, NoExtra::Args{});
+      else if constexpr (Op::kTileable && Op::kFilter) {  // (the ops that filter on pStar itself: lambda, delta-p)
+        if (ctx->splitBuild >= 4) {
+          uint2 *qp = ctx->qpos.as<uint2>();
+          hipLaunchKernelGGL((k_quantise<N>), g, b, 0, ctx->stream, c, Op::src(args), qp);
+          if (ctx->splitBuild == 4)
+            hipLaunchKernelGGL((k_build_lists_q<N, 2>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc);
+          else
+            hipLaunchKernelGGL((k_build_lists_q<N, 4>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc);
+        } else if (ctx->splitBuild == 2)
+          hipLaunchKernelGGL((k_build_lists<N, 4>), g, b, 0, ctx->stream, c, Op::src(args), args.type, key, table, nl, nc);
+        else
+          hipLaunchKernelGGL((k_build_lists<N, 8>), g, b, 0, ctx->stream, c, Op::src(args), args.type, key, table, nl, nc);
+      }
       hipLaunchKernelGGL((k_gather_from_lists<N, Op>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
     } else if (mode == GATHER_SAVE_LISTS) {
       hipLaunchKernelGGL((k_gather_lists<N, Op, 16, true>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
@@ -669,6 +691,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   else if (n == "tile_cap") ctx->tileCap = uint32_t(value);
   else if (n == "reuse_lists") ctx->reuseLists = value != 0;
   else if (n == "fuse_diffuse") ctx->fuseDiffuse = value != 0;
+  else if (n == "split_build") ctx->splitBuild = int(value);
   else if (n == "timing_mask") ctx->timingMask = uint32_t(value);
   else if (n == "pad_lds") ctx->padLds = uint32_t(value);
   else return fail(ctx, PBF_ERR_INVALID, "unknown option " + n);
@@ -718,6 +741,7 @@ int pbf_create(const pbf_desc *desc, pbf_ctx **out) {
   if (const char *e = std::getenv("PBF_TILE_CAP")) ctx->tileCap = uint32_t(std::atoi(e));
   if (const char *e = std::getenv("PBF_GATHER")) ctx->gatherKind = std::atoi(e);
   if (const char *e = std::getenv("PBF_REUSE_LISTS")) ctx->reuseLists = std::atoi(e) != 0;
+  if (const char *e = std::getenv("PBF_SPLIT_BUILD")) ctx->splitBuild = std::atoi(e);
   if (const char *e = std::getenv("PBF_LIST_MAX")) ctx->listMax = uint32_t(std::atoi(e));
   if ((e = hipSetDevice(ctx->device)) != hipSuccess) {
     g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
@@ -752,7 +776,7 @@ void pbf_destroy(pbf_ctx *ctx) {
                    &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2], &ctx->count, &ctx->table,   &ctx->blockSums,
                    &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl,
                    &ctx->latticePN, &ctx->latticeC, &ctx->mcCounts, &ctx->mcOffsets, &ctx->mcSums, &ctx->meshV, &ctx->meshN,
-                   &ctx->meshC, &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR};
+                   &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR};
   for (DevBuf *b : all)
     if (b->p) (void)hipFree(b->p);
   if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);

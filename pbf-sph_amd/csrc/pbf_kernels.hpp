@@ -336,7 +336,7 @@ template <typename N> struct DiffuseOp {
   static constexpr bool kFilter = false;             // no distance test in diffuse: every candidate counts
   static constexpr bool kTileable = true;            // has a single source array the brick kernel can stage
   __device__ bool near(const StepConsts<N> &, const Src &) const { return true; }
-  __device__ static const Src *src(const Args &a) { return a.colIn; }
+  __host__ __device__ static const Src *src(const Args &a) { return a.colIn; }
   __device__ static Src load(const Args &a, uint32_t b) { return a.colIn[b]; }
   vec4<N> ca;
   N mx, my, mz, mw;
@@ -386,7 +386,7 @@ template <typename N, bool FAST> struct LambdaOp {
   static constexpr bool kFilter = true;
   static constexpr bool kTileable = true;
   __device__ bool near(const StepConsts<N> &c, const Src &pb) const { return maybe_within_h<N>(pa, pb, c.h2filter); }
-  __device__ static const Src *src(const Args &a) { return a.pstar; }
+  __host__ __device__ static const Src *src(const Args &a) { return a.pstar; }
   __device__ static Src load(const Args &a, uint32_t b) { return a.pstar[b]; }
   vec4<N> pa;
   N mass, gx, gy, gz, rho;
@@ -443,7 +443,7 @@ template <typename N, bool FAST> struct DeltaOp {
   static constexpr bool kFilter = true;
   static constexpr bool kTileable = true;
   __device__ bool near(const StepConsts<N> &c, const Src &pb) const { return maybe_within_h<N>(pa, pb, c.h2filter); }
-  __device__ static const Src *src(const Args &a) { return a.pstarIn; }
+  __host__ __device__ static const Src *src(const Args &a) { return a.pstarIn; }
   __device__ static Src load(const Args &a, uint32_t b) { return a.pstarIn[b]; }
   vec4<N> pa;
   N ax, ay, az;
@@ -845,7 +845,8 @@ constexpr uint32_t NBR_OVERFLOW = 0xFFFFFFFFu;
 struct NoExtra {
   struct Args {};
 };
-template <typename N, typename Op, int LMAX, bool SAVE = false, typename Extra = NoExtra>
+// BUILD_ONLY: only build and save the lists (no pair terms, no output) — the op then runs list-driven.
+template <typename N, typename Op, int LMAX, bool SAVE = false, typename Extra = NoExtra, bool BUILD_ONLY = false>
 __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typename Op::Args args,
                                                         const uint32_t *__restrict__ key,
                                                         const uint32_t *__restrict__ table,
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
       const bool valid = q < nl;
       const uint32_t b = valid ? list[q * BLOCK + tid] : i;
       if (SAVE && valid && written + q < NBR_CAP) mine[(written + q) * BLOCK] = b;
-      op.add_bf(c, Op::load(args, b), valid);
+      if (!BUILD_ONLY) op.add_bf(c, Op::load(args, b), valid);
     }
     written += nl;
     nl = 0;
@@ -929,8 +930,248 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
     }
   drain();
   if (SAVE) nbrCount[i] = written <= NBR_CAP ? written : NBR_OVERFLOW;
-  op.end(c, args, i);
+  if (!BUILD_ONLY) op.end(c, args, i);
   if constexpr (FUSED) extra.end(c, xargs, i);
+}
+
+// Neighbour-list build on its own (no pair terms): the walk is latency-bound — table entry ->
+// candidate position -> test, 27 times in a row — so this kernel is shaped for loads in flight:
+//   * the three x-cells of a (dy, dz) row are walked as ONE candidate sequence (two runs of the sorted
+//     array, slot -> index by one compare; order unchanged: x fastest), WAYS candidates per trip, so
+//     a row of ~12 candidates costs two trips of eight loads instead of six trips of four;
+//   * the next row's six table entries are loaded before the current row is walked;
+//   * no accumulators: survivors of the conservative test are staged per lane in LDS and flushed to
+//     the block's [slot][thread] list in HBM a slot at a time (one dense store per slot; a store per
+//     hit was measured 20 % slower), which lambda and delta-p then both read (k_gather_from_lists).
+template <typename N, int WAYS, int LMAX = 16>
+__global__ __launch_bounds__(BLOCK) void k_build_lists(StepConsts<N> c, const vec4<N> *__restrict__ pstar,
+                                                       const uint8_t *__restrict__ type,
+                                                       const uint32_t *__restrict__ key,
+                                                       const uint32_t *__restrict__ table,
+                                                       uint32_t *__restrict__ nbrList,
+                                                       uint32_t *__restrict__ nbrCount) {
+  __shared__ uint32_t list[(LMAX + WAYS) * BLOCK];  // per-lane staging: a trip appends up to WAYS past LMAX - 1
+  const uint32_t tid = threadIdx.x;
+  const uint32_t i = blockIdx.x * BLOCK + tid;
+  if (i >= c.n) return;
+  if (c.hasObstacles && type[i] != 0) {  // obstacles and ghost copies gather nothing (the ops' begin() agrees)
+    nbrCount[i] = 0;
+    return;
+  }
+  // 32-bit byte offsets from a uniform base (the host checks n * sizeof(vec4) < 2^32): one shift per address
+  const char *pbase = reinterpret_cast<const char *>(pstar);
+  auto position = [&](uint32_t b) { return *reinterpret_cast<const vec4<N> *>(pbase + b * uint32_t(sizeof(vec4<N>))); };
+  const vec4<N> pa = position(i);
+  uint32_t *blk = nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK;
+  uint32_t written = 0, nl = 0;
+  // staged survivors go out together: entry q of every lane in one store instruction (wave-uniform trip count)
+  auto flush = [&]() {
+    for (uint32_t q = 0; __any(q < nl); ++q)
+      if (q < nl && written + q < NBR_CAP) blk[(written + q) * BLOCK + tid] = list[q * BLOCK + tid];
+    written += nl;
+    nl = 0;
+  };
+  const Neigh nb = neigh_codes(key[i]);
+  struct Row {
+    uint32_t s[3], e[3];
+  };
+  auto load_row = [&](int r) {
+    Row row;
+    const uint32_t yz = nb.ys[r % 3] | nb.zs[r / 3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const uint32_t code = nb.xs[dx] | yz;
+      row.s[dx] = row.e[dx] = 0;
+      if (code < c.tableN) {  // sph.hpp:206-208
+        row.s[dx] = table[code];
+        row.e[dx] = (code + 1u) < c.tableN ? table[code + 1u] : row.s[dx];
+      }
+    }
+    return row;
+  };
+  bool irregular = false;
+  Row next = load_row(0);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const Row row = next;
+    if (r < 8) next = load_row(r + 1);
+    // The row's three cells are at most TWO runs of the sorted array: x cells (2m, 2m + 1) have adjacent
+    // codes, so either (x-1, x) or (x, x+1) is one contiguous range.  Empty / out-of-table cells drop out.
+    const uint32_t l0 = row.e[0] - row.s[0], l1 = row.e[1] - row.s[1], l2 = row.e[2] - row.s[2];
+    uint32_t sA, lA, sB, lB;
+    if (l0 == 0u) sA = row.s[1], lA = l1, sB = row.s[2], lB = l2;
+    else if (row.e[0] == row.s[1]) sA = row.s[0], lA = l0 + l1, sB = row.s[2], lB = l2;
+    else if (l1 == 0u) sA = row.s[0], lA = l0, sB = row.s[2], lB = l2;
+    else {
+      sA = row.s[0], lA = l0, sB = row.s[1], lB = l1 + l2;
+      irregular |= (l2 != 0u) && (row.e[1] != row.s[2]);  // cannot happen with a Morton table; see below
+    }
+    const uint32_t L = lA + lB, oB = sB - lA;  // slot -> index: slot + (slot < lA ? sA : oB), x fastest as before
+    for (uint32_t t = 0; __any(t < L); t += WAYS) {
+      if (t < L) {
+        uint32_t b[WAYS];
+        vec4<N> cnd[WAYS];
+#pragma unroll
+        for (uint32_t w = 0; w < WAYS; ++w) {
+          const uint32_t sl = min(t + w, L - 1u);  // a tail slot re-reads the last candidate and is masked
+          b[w] = sl + (sl < lA ? sA : oB);
+          cnd[w] = position(b[w]);
+        }
+#pragma unroll
+        for (uint32_t w = 0; w < WAYS; ++w) {
+          const bool hit = (t + w < L) & maybe_within_h<N>(pa, cnd[w], c.h2filter);
+          list[nl * BLOCK + tid] = b[w];  // branch-free append: the slot is kept only on a hit
+          nl += hit ? 1u : 0u;
+        }
+      }
+      if (__any(nl >= uint32_t(LMAX))) flush();
+    }
+  }
+  flush();
+  // a row that is not two runs (never with a table built by stage_sort) falls back to the cell walk
+  nbrCount[i] = (written <= NBR_CAP && !irregular) ? written : NBR_OVERFLOW;
+}
+
+// ---- the same build on 8-byte quantised positions -------------------------------------------------
+// The build is bound by the texture-address path (64 lanes x 16 B per candidate load), so the test
+// runs on a compact copy of pStar: per axis the LOW 16 bits of floor((p - gridMin) * 2048 / h).
+// Differences are taken modulo 2^16 (v_pk_sub_i16), i.e. exact whenever the true separation is below
+// 16 h, and squared-summed with two v_dot2 — 5 VALU per candidate, half the bytes.  The result is only
+// ever a SUPERSET of the particles within h (rounding is covered by the threshold, wrap-around and
+// overflow can only add far candidates); the list-driven ops apply the exact tests, so the physics
+// stays bit-identical.  A walker whose own coordinates are unusable (outside +-2^22 units) takes all.
+constexpr int QPOS_BITS = 11;                       // sub-cell resolution h / 2048
+constexpr uint32_t QPOS_T = (1u << QPOS_BITS) + 4;  // h (1 + 1e-5) + sqrt(3) (two floors) + 1 (fp rounding) < T
+typedef short qpair __attribute__((ext_vector_type(2)));
+
+template <typename N> __device__ inline uint2 quantise_position(const StepConsts<N> &c, const vec4<N> &p, bool *usable) {
+  const N k = N(1u << QPOS_BITS) / c.h;
+  const N fx = floor((p.x - c.minExtent[0]) * k), fy = floor((p.y - c.minExtent[1]) * k),
+          fz = floor((p.z - c.minExtent[2]) * k);
+  const N lim = N(1 << 22);
+  *usable = fabs(fx) < lim && fabs(fy) < lim && fabs(fz) < lim;  // (false for NaN too)
+  const uint32_t x = uint32_t(int32_t(fx)), y = uint32_t(int32_t(fy)), z = uint32_t(int32_t(fz));
+  return make_uint2((x & 0xFFFFu) | (y << 16), z & 0xFFFFu);
+}
+
+template <typename N>
+__global__ __launch_bounds__(BLOCK) void k_quantise(StepConsts<N> c, const vec4<N> *__restrict__ pstar,
+                                                    uint2 *__restrict__ qpos) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= c.n) return;
+  bool usable;
+  qpos[i] = quantise_position<N>(c, pstar[i], &usable);
+}
+
+// Two quantised candidates per load: the L1 works per cache line touched, not per byte, so the run is
+// walked in pairs (b, b + 1) fetched as one 16-byte load — a quarter of the load instructions of
+// the fp32 walk.  (qpos carries one spare entry: the pair of a run's last candidate may read past it.)
+struct __attribute__((aligned(8))) QPair {
+  uint32_t ax, ay, bx, by;  // two consecutive qpos entries
+};
+
+struct __attribute__((aligned(4))) TablePair {
+  uint32_t start, next;  // table[code], table[code + 1]
+};
+
+template <typename N, int W, int LMAX = 16>
+__global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const vec4<N> *__restrict__ pstar,
+                                                         const uint2 *__restrict__ qpos,
+                                                         const uint8_t *__restrict__ type,
+                                                         const uint32_t *__restrict__ key,
+                                                         const uint32_t *__restrict__ table,
+                                                         uint32_t *__restrict__ nbrList,
+                                                         uint32_t *__restrict__ nbrCount) {
+  __shared__ uint32_t list[(LMAX + 2 * W) * BLOCK];  // per-lane staging: a trip appends up to 2 W past LMAX - 1
+  const uint32_t tid = threadIdx.x;
+  const uint32_t i = blockIdx.x * BLOCK + tid;
+  if (i >= c.n) return;
+  if (c.hasObstacles && type[i] != 0) {
+    nbrCount[i] = 0;
+    return;
+  }
+  // 32-bit byte offsets from uniform bases: one shift per address
+  const char *qbase = reinterpret_cast<const char *>(qpos), *tbase = reinterpret_cast<const char *>(table);
+  bool usable;
+  const uint2 qa = quantise_position<N>(c, pstar[i], &usable);
+  const qpair axy = __builtin_bit_cast(qpair, qa.x), azw = __builtin_bit_cast(qpair, qa.y);
+  const uint32_t t2 = usable ? QPOS_T * QPOS_T : 0xFFFFFFFFu;
+  auto within = [&](uint32_t qx, uint32_t qy) {
+    const qpair dxy = __builtin_bit_cast(qpair, qx) - axy, dzw = __builtin_bit_cast(qpair, qy) - azw;
+    return uint32_t(__builtin_amdgcn_sdot2(dzw, dzw, __builtin_amdgcn_sdot2(dxy, dxy, 0, false), false)) <= t2;
+  };
+  uint32_t *blk = nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK;
+  uint32_t written = 0, nl = 0;
+  auto flush = [&]() {
+    for (uint32_t q = 0; __any(q < nl); ++q)
+      if (q < nl && written + q < NBR_CAP) blk[(written + q) * BLOCK + tid] = list[q * BLOCK + tid];
+    written += nl;
+    nl = 0;
+  };
+  const Neigh nb = neigh_codes(key[i]);
+  struct Row {
+    uint32_t s[3], l[3];
+  };
+  auto load_row = [&](int r) {
+    Row row;
+    const uint32_t yz = nb.ys[r % 3] | nb.zs[r / 3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const uint32_t code = nb.xs[dx] | yz;
+      // one 8-byte load per cell (the table keeps entries up to tableN + 1); a cell outside the table, and
+      // the table's last cell, are empty (sph.hpp:206-208) — their start is then never used
+      const TablePair tp = *reinterpret_cast<const TablePair *>(tbase + min(code, c.tableN) * 4u);
+      row.s[dx] = tp.start;
+      row.l[dx] = (code + 1u) < c.tableN ? tp.next - tp.start : 0u;
+    }
+    return row;
+  };
+  bool irregular = false;
+  Row next = load_row(0);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const Row row = next;
+    if (r < 8) next = load_row(r + 1);
+    // the row as two runs of the sorted array (see k_build_lists)
+    const uint32_t l0 = row.l[0], l1 = row.l[1], l2 = row.l[2];
+    uint32_t sA, lA, sB, lB;
+    if (l0 == 0u) sA = row.s[1], lA = l1, sB = row.s[2], lB = l2;
+    else if (row.s[0] + l0 == row.s[1]) sA = row.s[0], lA = l0 + l1, sB = row.s[2], lB = l2;
+    else if (l1 == 0u) sA = row.s[0], lA = l0, sB = row.s[2], lB = l2;
+    else {
+      sA = row.s[0], lA = l0, sB = row.s[1], lB = l1 + l2;
+      irregular |= (l2 != 0u) && (row.s[1] + l1 != row.s[2]);
+    }
+    // One slot sequence for the row, walked in PAIRS (slot 2j, 2j + 1 -> one 16-byte load): run A is
+    // padded to an even length so that no pair straddles the two runs; the pad slot is masked.
+    const uint32_t lAe = (lA + 1u) & ~1u, L = lAe + lB, oB = sB - lAe;
+    for (uint32_t t = 0; __any(t < L); t += 2 * W) {
+      if (t < L) {
+        uint32_t b[W], lim[W];
+        QPair cnd[W];
+#pragma unroll
+        for (uint32_t w = 0; w < W; ++w) {
+          const uint32_t sl = min(t + 2 * w, L - 1u);  // a tail pair re-reads the last slot and is masked
+          const bool inA = sl < lAe;
+          b[w] = sl + (inA ? sA : oB);
+          lim[w] = inA ? lA : L;
+          cnd[w] = *reinterpret_cast<const QPair *>(qbase + b[w] * 8u);
+        }
+#pragma unroll
+        for (uint32_t w = 0; w < W; ++w) {
+          const bool hit0 = (t + 2 * w < lim[w]) & within(cnd[w].ax, cnd[w].ay);
+          list[nl * BLOCK + tid] = b[w];  // branch-free append: the slot is kept only on a hit
+          nl += hit0 ? 1u : 0u;
+          const bool hit1 = (t + 2 * w + 1 < lim[w]) & within(cnd[w].bx, cnd[w].by);
+          list[nl * BLOCK + tid] = b[w] + 1u;
+          nl += hit1 ? 1u : 0u;
+        }
+      }
+      if (__any(nl >= uint32_t(LMAX))) flush();
+    }
+  }
+  flush();
+  nbrCount[i] = (written <= NBR_CAP && !irregular) ? written : NBR_OVERFLOW;
 }
 
 // List-driven gather: the survivors recorded by the previous k_gather_lists<.., SAVE> launch on the

@@ -133,6 +133,25 @@ def test_free_running_bit_exact(pkg, oracle, scene, fp64, variant):
             assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
 
 
+@pytest.mark.parametrize("fp64", [False, True])
+@pytest.mark.parametrize("split", [0, 1, 2, 3, 4, 5])
+def test_split_build_bit_exact(pkg, oracle, split, fp64):
+    """Option split_build: 0 = lambda builds the neighbour lists while it gathers; 1..3 = a list-build launch of
+    its own (k_gather_lists build-only / k_build_lists 4- and 8-way) followed by a list-driven lambda.  Same
+    candidates in the same order either way — identical bits, obstacles and overflow rows included."""
+    sc, side = get_scene(pkg, "dam8192", fp64)
+    sc = {k: v.copy() for k, v in sc.items()}
+    sc["type"][::13] = 1
+    s, o = mk(pkg, oracle, sc, fp64, gather=1)
+    s.set_option("split_build", split)
+    p, q = params_pair(pkg, oracle, side=side)
+    for frame in range(6):
+        s.step(p)
+        o.step(q)
+        if frame in (0, 5):
+            assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
+
+
 def test_fused_diffuse_bit_exact(pkg, oracle):
     """Option fuse_diffuse: the colour diffusion rides on the first lambda launch's walk (same candidates,
     same order) — identical bits, obstacles included."""
