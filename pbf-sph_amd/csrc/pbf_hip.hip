@@ -82,7 +82,10 @@ struct pbf_ctx {
   DevBuf nbrList, nbrCount;  // neighbour lists handed from the lambda launch to the delta launch (NBR_CAP per particle)
   bool nbrValid = false;     // the lists describe pstar[pcur] as it is now
   bool reuseLists = true;    // option "reuse_lists"
-  int splitBuild = 0;   // option "split_build": list build and lambda as two launches
+  // option "split_build": 0 = lambda builds the neighbour lists while it gathers (k_gather_lists<SAVE>);
+  // otherwise the build is a launch of its own followed by a list-driven lambda: 1 = k_gather_lists build-only,
+  // 2 / 3 = k_build_lists 4- / 8-way on fp pStar, 4 / 5 = k_build_lists_q (quantised pairs) 2 / 4 loads per trip
+  int splitBuild = 5;
   bool fuseDiffuse = false;  // option "fuse_diffuse": pbf_step folds the diffuse walk into the first lambda launch
                              // (bit-identical; measured 2 % SLOWER at 1 M — the colour loads stall the filter loop — so off)
   bool fuseDiffuseNow = false;
@@ -156,7 +159,7 @@ int ensure_particles(pbf_ctx *ctx, size_t n) {
     if (int rc = ensure(ctx, ctx->pstar[s], n * v)) return rc;
   if (int rc = ensure(ctx, ctx->permTmp, n * 4)) return rc;
   if (int rc = ensure(ctx, ctx->slotOf, n * 4)) return rc;
-  if (int rc = ensure(ctx, ctx->qpos, n * 8 + 16)) return rc;
+  if (int rc = ensure(ctx, ctx->qpos, (n + QPOS_PAD) * 8)) return rc;
   if (int rc = ensure(ctx, ctx->nbrCount, n * 4)) return rc;
   if (int rc = ensure(ctx, ctx->nbrList, ((n + BLOCK - 1) / BLOCK) * size_t(NBR_CAP) * BLOCK * 4)) return rc;
   ctx->cap = n;

@@ -1071,8 +1071,24 @@ struct __attribute__((aligned(8))) QPair {
 };
 
 struct __attribute__((aligned(4))) TablePair {
-  uint32_t start, next;  // table[code], table[code + 1]
+  uint32_t t0, t1;  // table[code], table[code + 1]
 };
+struct __attribute__((aligned(4))) TableTriple {
+  uint32_t t0, t1, t2;  // table[code .. code + 2]
+};
+// |d|^2 of two packed int16 pairs: v_dot2_i32_i16 with an inline-zero / register addend (the builtin
+// lowers to the accumulate-in-place form and spends a v_mov on the zero)
+__device__ inline int qdot2(uint32_t d) {
+  int r;
+  asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(r) : "v"(d));
+  return r;
+}
+__device__ inline int qdot2(uint32_t d, int acc) {
+  int r;
+  asm("v_dot2_i32_i16 %0, %1, %1, %2" : "=v"(r) : "v"(d), "v"(acc));
+  return r;
+}
+constexpr uint32_t QPOS_PAD = 64;  // spare qpos entries: tail pairs of a run read (and mask) what follows it
 
 template <typename N, int W, int LMAX = 16>
 __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const vec4<N> *__restrict__ pstar,
@@ -1082,6 +1098,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const 
                                                          const uint32_t *__restrict__ table,
                                                          uint32_t *__restrict__ nbrList,
                                                          uint32_t *__restrict__ nbrCount) {
+  static_assert(4 * W + 2 <= QPOS_PAD, "qpos padding");
   __shared__ uint32_t list[(LMAX + 2 * W) * BLOCK];  // per-lane staging: a trip appends up to 2 W past LMAX - 1
   const uint32_t tid = threadIdx.x;
   const uint32_t i = blockIdx.x * BLOCK + tid;
@@ -1098,7 +1115,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const 
   const uint32_t t2 = usable ? QPOS_T * QPOS_T : 0xFFFFFFFFu;
   auto within = [&](uint32_t qx, uint32_t qy) {
     const qpair dxy = __builtin_bit_cast(qpair, qx) - axy, dzw = __builtin_bit_cast(qpair, qy) - azw;
-    return uint32_t(__builtin_amdgcn_sdot2(dzw, dzw, __builtin_amdgcn_sdot2(dxy, dxy, 0, false), false)) <= t2;
+    return uint32_t(qdot2(__builtin_bit_cast(uint32_t, dzw), qdot2(__builtin_bit_cast(uint32_t, dxy)))) <= t2;
   };
   uint32_t *blk = nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK;
   uint32_t written = 0, nl = 0;
@@ -1108,52 +1125,47 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const 
     written += nl;
     nl = 0;
   };
-  const Neigh nb = neigh_codes(key[i]);
+  // A (dy, dz) row of three x cells is TWO runs of the sorted array: the cells (2m, 2m + 1) have
+  // adjacent codes, so for an odd own x the row is [x-1, x] + [x+1], for an even one [x-1] + [x, x+1].
+  // Two loads per row: table[pair .. pair + 2] and table[single .. single + 1] (the table keeps entries
+  // up to tableN + 1).  A cell outside the table, and the table's last cell, are empty (sph.hpp:206-208).
+  const uint32_t k0 = key[i];
+  const Neigh nb = neigh_codes(k0);
+  const bool odd = (k0 & 1u) != 0u;
+  const uint32_t xPair = odd ? nb.xs[0] : nb.xs[1], xSingle = odd ? nb.xs[2] : nb.xs[0];
   struct Row {
-    uint32_t s[3], l[3];
+    uint32_t sA, lA, sB, lB;
   };
   auto load_row = [&](int r) {
-    Row row;
     const uint32_t yz = nb.ys[r % 3] | nb.zs[r / 3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const uint32_t code = nb.xs[dx] | yz;
-      // one 8-byte load per cell (the table keeps entries up to tableN + 1); a cell outside the table, and
-      // the table's last cell, are empty (sph.hpp:206-208) — their start is then never used
-      const TablePair tp = *reinterpret_cast<const TablePair *>(tbase + min(code, c.tableN) * 4u);
-      row.s[dx] = tp.start;
-      row.l[dx] = (code + 1u) < c.tableN ? tp.next - tp.start : 0u;
-    }
+    const uint32_t cP = xPair | yz, cS = xSingle | yz;
+    const TableTriple tp = *reinterpret_cast<const TableTriple *>(tbase + min(cP, c.tableN) * 4u);
+    const TablePair ts = *reinterpret_cast<const TablePair *>(tbase + min(cS, c.tableN) * 4u);
+    const uint32_t lP0 = (cP + 1u) < c.tableN ? tp.t1 - tp.t0 : 0u, lP1 = (cP + 2u) < c.tableN ? tp.t2 - tp.t1 : 0u;
+    const uint32_t sP = lP0 ? tp.t0 : tp.t1, lP = lP0 + lP1;
+    const uint32_t lS = (cS + 1u) < c.tableN ? ts.t1 - ts.t0 : 0u;
+    Row row;
+    row.sA = odd ? sP : ts.t0, row.lA = odd ? lP : lS;
+    row.sB = odd ? ts.t0 : sP, row.lB = odd ? lS : lP;
     return row;
   };
-  bool irregular = false;
   Row next = load_row(0);
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const Row row = next;
     if (r < 8) next = load_row(r + 1);
-    // the row as two runs of the sorted array (see k_build_lists)
-    const uint32_t l0 = row.l[0], l1 = row.l[1], l2 = row.l[2];
-    uint32_t sA, lA, sB, lB;
-    if (l0 == 0u) sA = row.s[1], lA = l1, sB = row.s[2], lB = l2;
-    else if (row.s[0] + l0 == row.s[1]) sA = row.s[0], lA = l0 + l1, sB = row.s[2], lB = l2;
-    else if (l1 == 0u) sA = row.s[0], lA = l0, sB = row.s[2], lB = l2;
-    else {
-      sA = row.s[0], lA = l0, sB = row.s[1], lB = l1 + l2;
-      irregular |= (l2 != 0u) && (row.s[1] + l1 != row.s[2]);
-    }
     // One slot sequence for the row, walked in PAIRS (slot 2j, 2j + 1 -> one 16-byte load): run A is
     // padded to an even length so that no pair straddles the two runs; the pad slot is masked.
-    const uint32_t lAe = (lA + 1u) & ~1u, L = lAe + lB, oB = sB - lAe;
+    const uint32_t lA = row.lA, lAe = (lA + 1u) & ~1u, L = lAe + row.lB, oB = row.sB - lAe;
     for (uint32_t t = 0; __any(t < L); t += 2 * W) {
       if (t < L) {
         uint32_t b[W], lim[W];
         QPair cnd[W];
 #pragma unroll
         for (uint32_t w = 0; w < W; ++w) {
-          const uint32_t sl = min(t + 2 * w, L - 1u);  // a tail pair re-reads the last slot and is masked
+          const uint32_t sl = t + 2 * w;  // slots past L read what follows run B (QPOS_PAD) and are masked
           const bool inA = sl < lAe;
-          b[w] = sl + (inA ? sA : oB);
+          b[w] = sl + (inA ? row.sA : oB);
           lim[w] = inA ? lA : L;
           cnd[w] = *reinterpret_cast<const QPair *>(qbase + b[w] * 8u);
         }
@@ -1171,7 +1183,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const 
     }
   }
   flush();
-  nbrCount[i] = (written <= NBR_CAP && !irregular) ? written : NBR_OVERFLOW;
+  nbrCount[i] = written <= NBR_CAP ? written : NBR_OVERFLOW;
 }
 
 // List-driven gather: the survivors recorded by the previous k_gather_lists<.., SAVE> launch on the
