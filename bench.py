@@ -161,7 +161,10 @@ def main():
     barrier()
     split = solver.stage_times()
     names = list(split)
-    dom_name = max(split, key=lambda k: split[k][0] * split[k][1]) if split_steps else "sph-lambda"
+    # an entry "stage/part" is one kernel inside "stage": the composite stage is then not a kernel of its own
+    composite = {k for k in split if any(o.startswith(k + "/") and split[o][1] > 0 for o in split)}
+    kernels = [k for k in split if k not in composite]
+    dom_name = max(kernels, key=lambda k: split[k][0] * split[k][1]) if split_steps else "sph-lambda"
     solver.set_option("timing_mask", 1 << names.index(dom_name) if dom_name in names else 0xFFFFFFFF)
     solver.reset_stage_times()
     t0 = time.perf_counter()
@@ -183,11 +186,20 @@ def main():
         total_particles = n * world
         value = total_particles * args.steps / elapsed
         sb = STAGE_BYTES_F64 if args.fp64 else STAGE_BYTES_F32
-        # dominant kernel = the stage with the largest total time per step
+        # dominant kernel = the kernel-level entry with the largest total time per step
         per_step = {k: ms * calls / max(split_steps, 1) for k, (ms, calls) in split.items()}  # last warm-up steps
         dom = dom_name
         dom_ms, dom_calls = stage[dom]  # the dominant stage: every launch of the timed region
-        achieved = sb[dom] * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        if dom == "sph-lambda/list-build":
+            # k_build_lists_q: own pStar + quantised position of every particle once + key in,
+            # list length + S list entries out per particle; S = mean length of the lists the last launch wrote
+            cnt = solver.nbr_counts()
+            mean_list = float(np.minimum(cnt, 64).mean())
+            dom_bytes = (32 if args.fp64 else 16) + 8 + 4 + 4 + 4 * mean_list
+        else:
+            mean_list = None
+            dom_bytes = sb[dom]
+        achieved = dom_bytes * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         bytes_step = (276 + 44 * args.solver_iter) if not args.fp64 else (528 + 88 * args.solver_iter)
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
         # WRITE_SIZE collected separately, 2 x FETCH gfx950 correction; profiles/r01_pmc_traffic.json) — only
@@ -195,9 +207,10 @@ def main():
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if world == 1 and not args.fp64 and args.particles == (1 << 20) and not args.fast_math and os.path.exists(tfile):
-            tag = {"sph-lambda": "LambdaOp", "sph-delta": "DeltaOp", "sph-diffuse": "DiffuseOp"}.get(dom)
+            tag = {"sph-lambda/list-build": "k_build_lists", "sph-lambda": "LambdaOp", "sph-delta": "DeltaOp",
+                   "sph-diffuse": "DiffuseOp"}.get(dom)
             for name, t in json.load(open(tfile)).items():
-                if tag and tag in name and "gather" in name:
+                if tag and tag in name:
                     traffic = t["hbm_bytes_gfx950_corrected"]
         out = {
             "metric": "particle-steps/sec (1 M particles, 4 iters) + achieved HBM GB/s, 1/2/4/8 MI355X",
@@ -222,8 +235,8 @@ def main():
                                       f"max rank load {imbalance:.2f}x mean"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_particle": sb[dom], "mean_launch_ms": dom_ms,
-                         "launches_timed": dom_calls,
+                         "algorithmic_bytes_per_particle": dom_bytes, "mean_list_length": mean_list,
+                         "mean_launch_ms": dom_ms, "launches_timed": dom_calls,
                          "whole_step_GBs": value * bytes_step / 1e9 / world,
                          "note": "neighbour kernels are LDS/VALU/latency-bound, not HBM-bound (SURVEY.md §8d)"},
             # the step's pure streams for contrast ("where >= 50 % of 8 TB/s is physically meaningful")
@@ -231,6 +244,11 @@ def main():
                                        "frac": sb[k] * n / (split[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        "algorithmic_bytes_per_particle": sb[k], "mean_launch_ms": split[k][0]}
                                    for k in ("sph-finalise", "advect+zindex") if k in split and split[k][0] > 0},
+            # the whole lambda stage (quantise + list build + list-driven lambda) against SURVEY.md §8d's 16 B/particle
+            "roofline_stage": {k: {"achieved": sb[k] * n / (split[k][0] * 1e-3) / 1e9, "unit": "GB/s",
+                                   "frac": sb[k] * n / (split[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "algorithmic_bytes_per_particle": sb[k], "mean_stage_ms": split[k][0]}
+                               for k in ("sph-lambda", "sph-delta") if k in split and split[k][0] > 0},
             "stage_ms_per_step": per_step,
             "stage_split_from": f"last {split_steps} warm-up steps (all stages bracketed); roofline: timed region",
         }

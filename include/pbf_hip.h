@@ -79,7 +79,8 @@ void pbf_destroy(pbf_ctx *ctx);
 const char *pbf_last_error(const pbf_ctx *ctx);
 int pbf_abi_version(void);
 /* Tuning / diagnostic knobs (no reference counterpart): "gather" (0 global walk, 1 filtered lists, 2 LDS bricks),
- * "list_max", "tile_cap", "reuse_lists", "fuse_diffuse", "timing_mask" (bit i = stage i of pbf_stage_times is bracketed with events).
+ * "list_max", "tile_cap", "reuse_lists", "split_build" (0 lambda builds the lists itself, 1-5 list-build launch variants,
+ * default 5), "cell_diffuse" (one colour walk per occupied cell, default 1), "fuse_diffuse", "timing_mask" (bit i = stage i of pbf_stage_times is bracketed with events).
  * Unknown names return PBF_ERR_INVALID. */
 int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value);
 
@@ -122,7 +123,9 @@ enum pbf_buffer {
   PBF_BUF_KEYS = 0,   /* uint32[n]  Morton cell key per particle, current device order */
   PBF_BUF_TABLE = 1,  /* uint32[table_size] = the reference's gridTable (sph.hpp:238-250) */
   PBF_BUF_PSTAR = 2,  /* N[4n]: pStar.xyz, lambda */
-  PBF_BUF_COUNT_ = 3,
+  PBF_BUF_NBR_COUNT = 3, /* uint32[n]: neighbour-list length per particle of the last list build (0xFFFFFFFF =
+                            the row overflowed and the particle walks its cells); diagnostic, list gather only */
+  PBF_BUF_COUNT_ = 4,
 };
 int pbf_read_buffer(pbf_ctx *ctx, int which, void *host, size_t bytes);
 size_t pbf_table_size(const pbf_ctx *ctx);                /* Morton(extent), sph.hpp:240 */
@@ -130,7 +133,9 @@ int pbf_grid_extent(const pbf_ctx *ctx, uint64_t extent[3], double min_extent[3]
 
 /* Mean milliseconds per call of each stage since the last pbf_reset_stage_times (needs
  * PBF_FLAG_STAGE_TIMING).  names[i] points at static strings that follow the reference's Stopwatch
- * entries (ompsph.hpp:130,157,161,188,209,252).  Returns the number of stages (<= cap). */
+ * entries (ompsph.hpp:130,157,161,188,209,252); an entry named "stage/part" is a sub-interval of "stage"
+ * (e.g. "sph-lambda/list-build": the neighbour-list kernel inside the lambda stage) and must not be added
+ * to it.  Returns the number of entries (<= cap). */
 int pbf_stage_times(pbf_ctx *ctx, const char **names, double *mean_ms, uint64_t *calls, int cap);
 int pbf_reset_stage_times(pbf_ctx *ctx);
 

@@ -14,6 +14,7 @@ FLAG_FAST_MATH = 1 << 1
 FLAG_NO_LDS = 1 << 2
 
 BUF_KEYS, BUF_TABLE, BUF_PSTAR = 0, 1, 2
+BUF_NBR_COUNT = 3
 
 
 class PbfError(RuntimeError):
@@ -276,6 +277,12 @@ class Solver:
     def stage(self, name, p):
         self._chk(getattr(self.L, "pbf_stage_" + name)(self.ctx, C.byref(p)), "pbf_stage_" + name)
         return self
+
+    def nbr_counts(self):
+        """Neighbour-list length per particle of the last list build (0xFFFFFFFF: overflowed row)."""
+        k = np.empty(self.n, np.uint32)
+        self._chk(self.L.pbf_read_buffer(self.ctx, BUF_NBR_COUNT, _vp(k), k.nbytes), "read neighbour counts")
+        return k
 
     def keys(self):
         k = np.empty(self.n, np.uint32)

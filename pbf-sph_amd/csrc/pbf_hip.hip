@@ -33,10 +33,11 @@ struct DevBuf {
 constexpr uint32_t kTickets = 255;
 constexpr int kBrickZ = 4;
 
-enum Stage { ST_PREDICT = 0, ST_SORT, ST_DIFFUSE, ST_LAMBDA, ST_DELTA, ST_FINALISE, ST_COUNT };
+enum Stage { ST_PREDICT = 0, ST_SORT, ST_DIFFUSE, ST_LAMBDA, ST_DELTA, ST_FINALISE, ST_BUILD, ST_COUNT };
 // names follow the reference's Stopwatch entries (ompsph.hpp:130,157,161,188,209,252)
 const char *kStageNames[ST_COUNT] = {"advect+zindex",      "sortz+gridtable", "sph-diffuse",
-                                     "sph-lambda",         "sph-delta",       "sph-finalise"};
+                                     "sph-lambda",         "sph-delta",       "sph-finalise",
+                                     "sph-lambda/list-build"};  // (a sub-interval of sph-lambda: one kernel)
 
 struct EventPair {
   hipEvent_t a, b;
@@ -86,6 +87,7 @@ struct pbf_ctx {
   // otherwise the build is a launch of its own followed by a list-driven lambda: 1 = k_gather_lists build-only,
   // 2 / 3 = k_build_lists 4- / 8-way on fp pStar, 4 / 5 = k_build_lists_q (quantised pairs) 2 / 4 loads per trip
   int splitBuild = 5;
+  bool cellDiffuse = true;   // option "cell_diffuse": one walk per occupied cell instead of one per particle
   bool fuseDiffuse = false;  // option "fuse_diffuse": pbf_step folds the diffuse walk into the first lambda launch
                              // (bit-identical; measured 2 % SLOWER at 1 M — the colour loads stall the filter loop — so off)
   bool fuseDiffuseNow = false;
@@ -419,6 +421,7 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
         if (ctx->splitBuild >= 4) {
           uint2 *qp = ctx->qpos.as<uint2>();
           hipLaunchKernelGGL((k_quantise<N>), g, b, 0, ctx->stream, c, Op::src(args), qp);
+          StageTimer tb(ctx, ST_BUILD);
           if (ctx->splitBuild == 4)
             hipLaunchKernelGGL((k_build_lists_q<N, 2>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc);
           else
@@ -485,7 +488,25 @@ template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p) {
   const int s = ctx->cur, d = 1 - s;  // col4[d] is free after the sort
   typename DiffuseOp<N>::Args args{ctx->col4[s].as<const vec4<N>>(), ctx->col4[d].as<vec4<N>>(),
                                    ctx->type[s].as<const uint8_t>()};
-  if (int rc = launch_gather<N, DiffuseOp<N>>(ctx, c, args)) return rc;
+  if (ctx->cellDiffuse) {
+    // sums per cell, parked in buffers that are idle here: the Jacobi partner of pStar and the list lengths
+    vec4<N> *cellSum = ctx->pstar[other_pstar(ctx)].as<vec4<N>>();
+    uint32_t *cellCnt = ctx->nbrCount.as<uint32_t>();
+    const uint32_t *key = ctx->key[s].as<const uint32_t>(), *table = ctx->table.as<const uint32_t>();
+    static_assert(kBrickZ == 4, "the sort stage's brick list is the 4 x 4 x 4 one");
+    const uint32_t cap = sizeof(vec4<N>) == 16 ? 3072u : 1536u;  // 48 KiB of colours: 216 cells x 14 (7) particles
+    const size_t lds = Brick<4>::HDR + size_t(cap) * sizeof(vec4<N>);
+    const uint32_t perCU = uint32_t((160 * 1024) / (lds + 1024));
+    hipLaunchKernelGGL((k_diffuse_bricks<N>), dim3(uint32_t(ctx->numCUs) * perCU), dim3(DIFFUSE_BRICK_THREADS), lds,
+                       ctx->stream, c, args.colIn, args.type, table, ctx->bricks.as<const uint32_t>(),
+                       ctx->brickCtl.as<const uint32_t>(), cellSum, cellCnt, cap);
+    hipLaunchKernelGGL((k_diffuse_apply<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table,
+                       cellSum, cellCnt);
+    LAUNCH_CHECK(ctx);
+    ctx->nbrValid = false;
+  } else if (int rc = launch_gather<N, DiffuseOp<N>>(ctx, c, args)) {
+    return rc;
+  }
   std::swap(ctx->col4[s], ctx->col4[d]);
   return PBF_OK;
 }
@@ -694,6 +715,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   else if (n == "tile_cap") ctx->tileCap = uint32_t(value);
   else if (n == "reuse_lists") ctx->reuseLists = value != 0;
   else if (n == "fuse_diffuse") ctx->fuseDiffuse = value != 0;
+  else if (n == "cell_diffuse") ctx->cellDiffuse = value != 0;
   else if (n == "split_build") ctx->splitBuild = int(value);
   else if (n == "timing_mask") ctx->timingMask = uint32_t(value);
   else if (n == "pad_lds") ctx->padLds = uint32_t(value);
@@ -919,6 +941,7 @@ int pbf_read_buffer(pbf_ctx *ctx, int which, void *host, size_t bytes) {
       src = ctx->table.p, avail = size_t(ctx->tableN) * 4;
       break;
     case PBF_BUF_PSTAR: src = ctx->pstar[ctx->pcur].p, avail = ctx->n * v; break;
+    case PBF_BUF_NBR_COUNT: src = ctx->nbrCount.p, avail = ctx->n * 4; break;
     default: return fail(ctx, PBF_ERR_INVALID, "unknown buffer");
   }
   if (bytes > avail) return fail(ctx, PBF_ERR_INVALID, "read beyond buffer");

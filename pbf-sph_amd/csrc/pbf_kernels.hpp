@@ -820,6 +820,167 @@ __global__ __launch_bounds__(THREADS) void k_gather_bricks(StepConsts<N> c, type
 }
 
 // ------------------------------------------------------------------------------------------------
+// Diffuse per CELL (option cell_diffuse, default on).  Diffuse has no distance test: a particle folds in
+// EVERY candidate of its 27 cells, in walk order, and only then looks at its own colour — so all the
+// particles of one cell accumulate the very same running sums, bit for bit.  One lane per occupied
+// cell does the walk once (k_diffuse_bricks; ~7 particles share a cell in the settled dam-break), the
+// sums are parked at the cell's first sorted slot, and k_diffuse_apply streams over the particles.
+// Particles outside the table (key >= tableN) keep their own walk.
+// ------------------------------------------------------------------------------------------------
+// The same per-cell sums with the candidates staged through LDS: one workgroup owns a Morton-aligned
+// brick of 4 x 4 x 4 cells (64 consecutive codes), copies the colours of its 6 x 6 x 6 halo of cells
+// into LDS once (x-fastest, so the three x cells of a row are ONE LDS run, like k_gather_bricks) and one
+// lane per home cell then folds its 9 runs in the reference's order.  One lane per cell straight from
+// global memory touches 64 different cache lines per load (measured: no faster than one lane per
+// particle); out of LDS the walk is bound by LDS bandwidth (64 cells x ~180 records x 16 B per brick;
+// a smaller tile with twice the workgroups per CU was measured: no faster).  A brick whose halo exceeds
+// `cap` records, or any brick when there are obstacles (candidate types), walks globally.
+template <typename N> __device__ inline void diffuse_cell_global(const StepConsts<N> &c, uint32_t code,
+                                                                 const vec4<N> *__restrict__ colIn,
+                                                                 const uint8_t *__restrict__ type,
+                                                                 const uint32_t *__restrict__ table,
+                                                                 vec4<N> *__restrict__ cellSum,
+                                                                 uint32_t *__restrict__ cellCnt) {
+  const uint32_t first = table[code];
+  if (table[code + 1u] == first) return;  // the TRUE count (the table keeps entry tableN): the last cell's walkers count
+  N mx = N(0), my = N(0), mz = N(0), mw = N(0);
+  uint32_t nn = 0;
+  auto add = [&](uint32_t b) {
+    const vec4<N> cb = colIn[b];
+    mx += cb.x, my += cb.y, mz += cb.z, mw += cb.w;
+    ++nn;
+  };
+  if (c.hasObstacles) {
+    for_each_candidate(code, table, c.tableN, [&](uint32_t b) {
+      if (!(type[b] & 1)) add(b);  // obstacles are skipped as candidates (ompsph.hpp:194)
+    });
+  } else {
+    for_each_candidate(code, table, c.tableN, add);
+  }
+  cellSum[first] = make_vec4<N>(mx, my, mz, mw);
+  cellCnt[first] = nn;
+}
+
+constexpr int DIFFUSE_BRICK_THREADS = 256;
+template <typename N>
+__global__ __launch_bounds__(DIFFUSE_BRICK_THREADS) void k_diffuse_bricks(StepConsts<N> c,
+                                                                          const vec4<N> *__restrict__ colIn,
+                                                                          const uint8_t *__restrict__ type,
+                                                                          const uint32_t *__restrict__ table,
+                                                                          const uint32_t *__restrict__ active,
+                                                                          const uint32_t *__restrict__ nActivePtr,
+                                                                          vec4<N> *__restrict__ cellSum,
+                                                                          uint32_t *__restrict__ cellCnt, uint32_t cap) {
+  using B = Brick<4>;
+  constexpr int THREADS = DIFFUSE_BRICK_THREADS;
+  static_assert(B::HALO <= THREADS && B::HOME <= THREADS, "one halo cell per thread");
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t *off = reinterpret_cast<uint32_t *>(smem);  // [HALO + 1]
+  uint32_t *gstart = off + B::HALO + 1;                // [HALO]
+  vec4<N> *tile = reinterpret_cast<vec4<N> *>(smem + B::HDR);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t nActive = *nActivePtr;
+  // persistent workgroups stride over the list of NON-EMPTY bricks (k_brick_list, built by the sort stage): a
+  // workgroup per brick of the whole table spends most of the launch retiring empty ones
+  for (uint32_t t = blockIdx.x; t < nActive; t += gridDim.x) {
+    __syncthreads();  // the previous brick's LDS reads are done before the header / tile are rewritten
+    const uint32_t code0 = active[t] * uint32_t(B::HOME);
+    // ---- the halo's cell ranges and their exclusive scan --------------------------------------------
+    const uint32_t bx = compact10(code0), by = compact10(code0 >> 1), bz = compact10(code0 >> 2);
+    uint32_t cnt = 0;
+    if (tid < B::HALO) {
+      const uint32_t lx = tid % 6, ly = (tid / 6) % 6, lz = tid / 36;
+      const uint32_t code = morton_encode((bx + lx - 1u) & 1023u, (by + ly - 1u) & 1023u, (bz + lz - 1u) & 1023u);
+      uint32_t s = 0, e = 0;
+      if (code < c.tableN) {  // sph.hpp:206-208
+        s = table[code];
+        e = (code + 1u) < c.tableN ? table[code + 1u] : s;
+      }
+      gstart[tid] = s;
+      cnt = e - s;
+    }
+    uint32_t total;
+    const uint32_t ex = block_excl_scan<THREADS>(cnt, &total);
+    if (tid < B::HALO) off[tid] = ex;
+    if (tid == 0) off[B::HALO] = total;
+    __syncthreads();
+    const uint32_t code = code0 + tid;
+    const bool home = tid < B::HOME && code < c.tableN;
+    if (total > cap || c.hasObstacles) {  // uniform
+      if (home) diffuse_cell_global<N>(c, code, colIn, type, table, cellSum, cellCnt);
+      continue;
+    }
+    // ---- stage the halo's colours (all threads, record r -> its halo cell by bisection of off[]) -----
+    constexpr uint32_t U = 8;  // loads in flight per thread: the whole halo is usually one batch
+    for (uint32_t base = tid; base < total; base += THREADS * U) {
+      vec4<N> v[U];
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) {
+        const uint32_t r = base + u * THREADS;
+        if (r < total) {
+          uint32_t h = 0;
+#pragma unroll
+          for (uint32_t step = 128; step >= 1; step >>= 1)
+            if (h + step <= uint32_t(B::HALO) && off[h + step] <= r) h += step;  // the last cell with off[h] <= r
+          v[u] = colIn[gstart[h] + (r - off[h])];
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) {
+        const uint32_t r = base + u * THREADS;
+        if (r < total) tile[r] = v[u];
+      }
+    }
+    __syncthreads();
+    // ---- one lane per home cell folds its 9 x-runs out of LDS, in the reference's order --------------
+    if (!home) continue;
+    const uint32_t first = table[code];
+    if (table[code + 1u] == first) continue;  // the TRUE count: the last cell's walkers count too
+    const uint32_t hx = (tid & 1u) | ((tid >> 2) & 2u), hy = ((tid >> 1) & 1u) | ((tid >> 3) & 2u),
+                   hz = ((tid >> 2) & 1u) | ((tid >> 4) & 2u);
+    N mx = N(0), my = N(0), mz = N(0), mw = N(0);
+    uint32_t nn = 0;
+#pragma unroll 1
+    for (uint32_t dz = 0; dz < 3; ++dz)
+#pragma unroll 1
+      for (uint32_t dy = 0; dy < 3; ++dy) {
+        const uint32_t l0 = ((hz + dz) * 6u + (hy + dy)) * 6u + hx;
+        const uint32_t s = off[l0], e = off[l0 + 3];
+#pragma unroll 8
+        for (uint32_t j = s; j < e; ++j) {
+          const vec4<N> cb = tile[j];
+          mx += cb.x, my += cb.y, mz += cb.z, mw += cb.w;
+        }
+        nn += e - s;
+      }
+    cellSum[first] = make_vec4<N>(mx, my, mz, mw);
+    cellCnt[first] = nn;
+  }
+}
+
+template <typename N>
+__global__ __launch_bounds__(BLOCK) void k_diffuse_apply(StepConsts<N> c, typename DiffuseOp<N>::Args args,
+                                                         const uint32_t *__restrict__ key,
+                                                         const uint32_t *__restrict__ table,
+                                                         const vec4<N> *__restrict__ cellSum,
+                                                         const uint32_t *__restrict__ cellCnt) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= c.n) return;
+  const uint32_t k = key[i];
+  if (k >= c.tableN) {  // in no cell (sph.hpp:206): nobody shares this walk
+    gather_one_global<N, DiffuseOp<N>>(c, args, key, table, i);
+    return;
+  }
+  DiffuseOp<N> op;
+  if (!op.begin(c, args, i)) return;
+  const uint32_t first = table[k];
+  const vec4<N> m = cellSum[first];
+  op.mx = m.x, op.my = m.y, op.mz = m.z, op.mw = m.w;
+  op.nn = int(cellCnt[first]);
+  op.end(c, args, i);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Gather kernel "lists" (option gather = 1, the default) — one lane per particle, candidates from
 // global memory (L1/L2), two phases:
 //   A  every lane walks its 27 cell ranges like the global kernel but only applies the conservative

@@ -152,6 +152,26 @@ def test_split_build_bit_exact(pkg, oracle, split, fp64):
             assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
 
 
+@pytest.mark.parametrize("cell", [0, 1])
+def test_cell_diffuse_bit_exact(pkg, oracle, cell):
+    """Option cell_diffuse (default 1): all particles of a cell share one colour walk (k_diffuse_bricks +
+    k_diffuse_apply) — the same running sums, so the same bits as one walk per particle (0), with and
+    without obstacles (which force the per-cell global walk)."""
+    for obstacles in (False, True):
+        sc, side = get_scene(pkg, "dam8192", False)
+        sc = {k: v.copy() for k, v in sc.items()}
+        sc["colour"][::3] = (0.9, 0.2, 0.1, 0.5)  # something to diffuse
+        if obstacles:
+            sc["type"][::13] = 1
+        s, o = mk(pkg, oracle, sc, False, gather=1)
+        s.set_option("cell_diffuse", cell)
+        p, q = params_pair(pkg, oracle, side=side)
+        for frame in range(5):
+            s.step(p)
+            o.step(q)
+        assert_state_equal(s.download(), o.get_particles(), f"cell={cell} obstacles={obstacles}")
+
+
 def test_fused_diffuse_bit_exact(pkg, oracle):
     """Option fuse_diffuse: the colour diffusion rides on the first lambda launch's walk (same candidates,
     same order) — identical bits, obstacles included."""
