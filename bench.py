@@ -30,6 +30,9 @@ STAGE_BYTES_F32 = {"advect+zindex": 52, "sortz+gridtable": 132, "sph-diffuse": 3
                    "sph-finalise": 60}
 STAGE_BYTES_F64 = {"advect+zindex": 100, "sortz+gridtable": 256, "sph-diffuse": 64, "sph-lambda": 32,
                    "sph-delta": 56, "sph-finalise": 120}
+# the kernel (rocprofv3 name) behind each timing entry of the default configuration
+KERNEL_OF = {"sph-lambda/list-build": "k_build_lists_q", "sph-delta": "k_gather_from_lists<DeltaOp>",
+             "sph-finalise": "k_finalise", "advect+zindex": "k_predict"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -233,12 +236,12 @@ def main():
                                       f"{world} x-slabs, one rank per GPU, 1-cell ghost layer refreshed after every "
                                       f"lambda/delta launch over RCCL ({backend}); {world} columns side by side, odd ones mirrored; "
                                       f"max rank load {imbalance:.2f}x mean"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stopwatch_entry": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_particle": dom_bytes, "mean_list_length": mean_list,
                          "mean_launch_ms": dom_ms, "launches_timed": dom_calls,
                          "whole_step_GBs": value * bytes_step / 1e9 / world,
-                         "note": "neighbour kernels are LDS/VALU/latency-bound, not HBM-bound (SURVEY.md §8d)"},
+                         "note": "the neighbour kernels are instruction-issue / LDS / latency bound, not HBM-bound (SURVEY.md §8d)"},
             # the step's pure streams for contrast ("where >= 50 % of 8 TB/s is physically meaningful")
             "roofline_streaming": {k: {"achieved": sb[k] * n / (split[k][0] * 1e-3) / 1e9, "unit": "GB/s",
                                        "frac": sb[k] * n / (split[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -465,8 +465,11 @@ def test_stage_timing(pkg):
     p = pkg.default_params(4, side)
     s.steps(p, 3)
     t = s.stage_times()
-    assert set(t) == {"advect+zindex", "sortz+gridtable", "sph-diffuse", "sph-lambda", "sph-delta", "sph-finalise"}
+    stages = {"advect+zindex", "sortz+gridtable", "sph-diffuse", "sph-lambda", "sph-delta", "sph-finalise"}
+    # "stage/part" entries are single kernels inside a stage (the neighbour-list build of the lambda stage)
+    assert {k for k in t if "/" not in k} == stages and set(t) - stages == {"sph-lambda/list-build"}
     assert t["sph-lambda"][1] == 12 and t["sph-delta"][1] == 12 and t["advect+zindex"][1] == 3
+    assert t["sph-lambda/list-build"][1] == 12 and 0 < t["sph-lambda/list-build"][0] < t["sph-lambda"][0]
     assert all(ms > 0 for ms, _ in t.values())
 
 
