@@ -1202,7 +1202,10 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists(StepConsts<N> c, const ve
 // overflow can only add far candidates); the list-driven ops apply the exact tests, so the physics
 // stays bit-identical.  A walker whose own coordinates are unusable (outside +-2^22 units) takes all.
 constexpr int QPOS_BITS = 11;                       // sub-cell resolution h / 2048
-constexpr uint32_t QPOS_T = (1u << QPOS_BITS) + 4;  // h (1 + 1e-5) + sqrt(3) (two floors) + 1 (fp rounding) < T
+// Threshold: a pair the exact test accepts has |d| <= 2048 (1 + 1e-5) units; per axis the quantised difference
+// is off by < 1 (two floors) + 1.5 (fp32 rounding of (p - min) * k for |coordinate| < 2^22 units: 3 roundings
+// of <= 0.25 each, two particles), so |dq| < 2048.03 + 2.5 sqrt(3) = 2052.4 < T.
+constexpr uint32_t QPOS_T = (1u << QPOS_BITS) + 5;
 typedef short qpair __attribute__((ext_vector_type(2)));
 
 template <typename N> __device__ inline uint2 quantise_position(const StepConsts<N> &c, const vec4<N> &p, bool *usable) {
