@@ -488,7 +488,7 @@ template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p) {
   const int s = ctx->cur, d = 1 - s;  // col4[d] is free after the sort
   typename DiffuseOp<N>::Args args{ctx->col4[s].as<const vec4<N>>(), ctx->col4[d].as<vec4<N>>(),
                                    ctx->type[s].as<const uint8_t>()};
-  if (ctx->cellDiffuse) {
+  if (ctx->cellDiffuse && !(ctx->desc.flags & PBF_FLAG_NO_LDS)) {
     // sums per cell, parked in buffers that are idle here: the Jacobi partner of pStar and the list lengths
     vec4<N> *cellSum = ctx->pstar[other_pstar(ctx)].as<vec4<N>>();
     uint32_t *cellCnt = ctx->nbrCount.as<uint32_t>();

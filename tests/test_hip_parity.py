@@ -172,6 +172,17 @@ def test_cell_diffuse_bit_exact(pkg, oracle, cell):
         assert_state_equal(s.download(), o.get_particles(), f"cell={cell} obstacles={obstacles}")
 
 
+def test_no_lds_flag_bit_exact(pkg, oracle):
+    """PBF_FLAG_NO_LDS: every gather stage (diffuse included) is the plain one-lane-per-particle walk."""
+    sc, side = get_scene(pkg, "dam8192", False)
+    s, o = mk(pkg, oracle, sc, False, flags=pkg.FLAG_NO_LDS, gather=1)
+    p, q = params_pair(pkg, oracle, side=side)
+    for frame in range(4):
+        s.step(p)
+        o.step(q)
+    assert_state_equal(s.download(), o.get_particles())
+
+
 def test_fused_diffuse_bit_exact(pkg, oracle):
     """Option fuse_diffuse: the colour diffusion rides on the first lambda launch's walk (same candidates,
     same order) — identical bits, obstacles included."""
