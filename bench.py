@@ -36,6 +36,32 @@ KERNEL_OF = {"sph-lambda/list-build": "k_build_lists_q", "sph-delta": "k_gather_
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def candidates_per_particle(keys, table):
+    """Mean number of candidates a particle's 27-cell walk visits (SURVEY.md §8d "C"), from the sorted Morton keys
+    and the grid table of the last step: for every particle the populations of its 27 cells, with the reference's
+    rules — a cell outside the table, and the table's last cell, are empty (sph.hpp:206-208)."""
+    keys = np.asarray(keys, np.int64)
+    table = np.asarray(table, np.int64)
+    tn = len(table)
+    inside = keys[keys < tn]
+    cnt = np.bincount(inside, minlength=tn)
+    cnt[-1] = 0
+    mx, my, mz = 0x09249249, 0x12492492, 0x24924924
+
+    def nb(m, unit):
+        a = keys & m
+        return [(a - unit) & m, a, ((a | (~m & 0x3FFFFFFF)) + unit) & m]
+
+    xs, ys, zs = nb(mx, 1), nb(my, 2), nb(mz, 4)
+    total = np.zeros(len(keys), np.int64)
+    for x in xs:
+        for y in ys:
+            for z in zs:
+                code = x | y | z
+                total += np.where(code < tn, cnt[np.minimum(code, tn - 1)], 0)
+    return float(total.mean()) if len(keys) else 0.0
+
+
 def load_package():
     pkg_dir = os.path.join(ROOT, "pbf-sph_amd")
     spec = importlib.util.spec_from_file_location("pbf_sph_amd", os.path.join(pkg_dir, "__init__.py"),
@@ -255,6 +281,16 @@ def main():
             "stage_ms_per_step": per_step,
             "stage_split_from": f"last {split_steps} warm-up steps (all stages bracketed); roofline: timed region",
         }
+        if world == 1:
+            # SURVEY.md §8(d)'s secondary figure: C candidates per particle are distance-tested once per solver
+            # iteration (the list build); the S that survive get exact pair terms twice (lambda, delta-p)
+            try:
+                C = candidates_per_particle(solver.keys(), solver.table())
+                rate = value * args.solver_iter
+                out["pairs"] = {"candidates_per_particle": C, "candidate_tests_per_s": rate * C,
+                                "pair_terms_per_s": (rate * 2 * mean_list) if mean_list is not None else None}
+            except Exception as e:  # diagnostic only
+                out["pairs"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:
             state = solver.download()
             cb, o = cpu_baseline(state, side, args.fp64, args.solver_iter)
