@@ -133,8 +133,8 @@ def test_free_running_bit_exact(pkg, oracle, scene, fp64, variant):
             assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
 
 
-@pytest.mark.parametrize("fp64", [False, True])
-@pytest.mark.parametrize("split", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("split,fp64", [(0, False), (1, False), (2, False), (3, False), (4, False), (5, False),
+                                        (0, True), (3, True), (5, True)])
 def test_split_build_bit_exact(pkg, oracle, split, fp64):
     """Option split_build: 0 = lambda builds the neighbour lists while it gathers; 1..3 = a list-build launch of
     its own (k_gather_lists build-only / k_build_lists 4- and 8-way) followed by a list-driven lambda.  Same
