@@ -2,6 +2,7 @@
 """bench.py — particle-steps/s of the PBF-SPH hot path on MI355X (BASELINE.json metric).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--particles P] [--fp64] [--fast-math]
+                  [--scaling weak|strong] [--settle-to F]
 
 A "step" is one advance() (predict+key, counting sort + cell table, diffuse, K_s = 4 x (lambda,
 delta-p), finalise) over the device-resident particle state of the dam-break scene
@@ -9,14 +10,27 @@ delta-p), finalise) over the device-resident particle state of the dam-break sce
 resident in HBM when the timed region starts; the PCIe-inclusive advance() rate is reported
 separately by the C++ benchmark CLI and in DESIGN.md, never as `value`.
 
+Frames of one run (nothing is measured in the first frames of the process — code-object load, cold clocks and
+the 1.84x over-dense start lattice's blow-up are not the workload):
+    settle   max(0, F - W) untimed frames, F = --settle-to, default 200 = the reference CLI's own warm-up
+             (args.hpp:36, benchmark.cpp:31-54: warm-up loop, then timed loop) — flag-independent regime
+    warm-up  W untimed frames (their last ones are bracketed stage by stage to find the dominant kernel)
+    timed    EXACTLY K frames = simulation frames [max(F, W), max(F, W) + K), barrier + synchronize on both sides
+    split    10 more untimed frames with every stage bracketed by HIP events: the per-stage split
+
+With --gpus N > 1 and no WORLD_SIZE in the environment this script starts its own N ranks (fresh processes,
+one per GPU, before anything touches the GPU); under torchrun it uses the ranks it is given.
+
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     — the dominant kernel's algorithmic bytes / its mean HIP-event duration
+  roofline     — the dominant kernel's algorithmic bytes / its mean HIP-event duration (solver stream)
   cpu_baseline — the CPU oracle (kind "port", OpenMP) timed on a bounded sample of the same workload.
 """
 import argparse
 import importlib.util
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,8 +46,12 @@ STAGE_BYTES_F64 = {"advect+zindex": 100, "sortz+gridtable": 256, "sph-diffuse": 
                    "sph-delta": 56, "sph-finalise": 120}
 # the kernel (rocprofv3 name) behind each timing entry of the default configuration
 KERNEL_OF = {"sph-lambda/list-build": "k_build_lists_q", "sph-delta": "k_gather_from_lists<DeltaOp>",
+             "sph-lambda/gather": "k_gather_from_lists<LambdaOp>",
              "sph-finalise": "k_finalise", "advect+zindex": "k_predict"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+SPLIT_STEPS = 10
+PROBE_STEPS = 10
+TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
 def candidates_per_particle(keys, table):
@@ -62,6 +80,12 @@ def candidates_per_particle(keys, table):
     return float(total.mean()) if len(keys) else 0.0
 
 
+def frame_plan(steps, warmup, settle_to):
+    """(settle, first timed frame): the timed region covers simulation frames [first, first + steps)."""
+    settle = max(0, settle_to - warmup)
+    return settle, settle + warmup
+
+
 def load_package():
     pkg_dir = os.path.join(ROOT, "pbf-sph_amd")
     spec = importlib.util.spec_from_file_location("pbf_sph_amd", os.path.join(pkg_dir, "__init__.py"),
@@ -72,17 +96,10 @@ def load_package():
     return mod
 
 
-def cpu_baseline(state, side, fp64, iteration, budget_s=20.0, max_steps=8):
-    """Time the oracle (the checker, kind 'port') on the host cores: a bounded sample of the SAME
-    workload, started from the GPU's post-warm-up state.  Reported, never optimised against."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-
-    threads = len(os.sched_getaffinity(0))
-    o = O.Oracle(fp64)
+def _time_oracle(O, so_path, state, side, fp64, iteration, threads, budget_s, max_steps):
+    o = O.Oracle(fp64, so_path=so_path)
     o.set_particles(**state)
     q = O.make_params(iteration=iteration, max_bound=(side,) * 3, mode=O.JACOBI, sort=O.SORT_STABLE, threads=threads)
-    n = len(state["id"])
     t0 = time.perf_counter()
     o.step(q)  # untimed: first touch / OpenMP pool start
     first = time.perf_counter() - t0
@@ -92,10 +109,76 @@ def cpu_baseline(state, side, fp64, iteration, budget_s=20.0, max_steps=8):
         o.step(q)
         t += time.perf_counter() - a
         steps += 1
-    return {"value": n * steps / t, "unit": "particle-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} steps of the same {n}-particle dam-break state after warm-up "
-                      f"(oracle Jacobi mode, OpenMP, -O2 no fast-math), {t:.1f} s",
-            "ms_per_step": 1e3 * t / steps}, o
+    return steps, t
+
+
+def cpu_baseline(state, side, fp64, iteration, budget_s=9.0, max_steps=6):
+    """Time the oracle (the checker's source, kind 'port') on the host cores: a bounded sample of the SAME workload,
+    started from the GPU's post-run state.  BASELINE.md §4: -O3 -march=native without fast-math is `value`; the
+    reference's Release flags (-Ofast -march=native, CMakeLists.txt:136) are reported beside it.  Both are compiled
+    on this box (oracle/Makefile `native`).  Reported, never optimised against."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    threads = len(os.sched_getaffinity(0))
+    n = len(state["id"])
+    try:
+        native = O.build_native()
+        builds = [("-O3 -march=native -fno-fast-math", native["O3"]), ("-Ofast -march=native", native["Ofast"])]
+    except Exception as e:  # no compiler on the box: fall back to the checker build that travelled with the repo
+        builds = [(f"-O2 -fno-fast-math (native build failed: {type(e).__name__})", None)]
+    res = []
+    for flags, path in builds:
+        steps, t = _time_oracle(O, path, state, side, fp64, iteration, threads, budget_s, max_steps)
+        res.append({"flags": flags, "value": n * steps / t, "ms_per_step": 1e3 * t / steps, "steps": steps, "seconds": t})
+    main = res[0]
+    out = {"value": main["value"], "unit": "particle-steps/s", "cores": threads, "kind": "port",
+           "sample": f"{main['steps']} steps of the same {n}-particle dam-break state after the timed region "
+                     f"(oracle Jacobi mode, OpenMP, {main['flags']}), {main['seconds']:.1f} s",
+           "ms_per_step": main["ms_per_step"], "flags": main["flags"]}
+    if len(res) > 1:
+        out["reference_release_flags"] = {"flags": res[1]["flags"], "value": res[1]["value"],
+                                          "ms_per_step": res[1]["ms_per_step"], "steps": res[1]["steps"]}
+    return out, O
+
+
+def launch_ranks(args):
+    """--gpus N without torchrun: start N fresh rank processes of this script (one per GPU) BEFORE this process
+    touches the GPU; rank 0 prints the JSON line.  Exit code = the first failing rank's."""
+    import torch  # counting devices does not initialise the GPU
+
+    have = torch.cuda.device_count()
+    backend = os.environ.get("PBF_BENCH_BACKEND", "nccl")
+    if have < args.gpus and backend == "nccl":
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PBF_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("PBF_BENCH_TIMEOUT", "1500"))
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in procs:  # one rank died: the others would wait in a collective for ever
+                    q.terminate()
+        if time.time() > deadline:
+            for q in procs:
+                q.kill()
+            return rc or 124
+        time.sleep(0.05)
+    return rc
 
 
 def main():
@@ -103,21 +186,32 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--particles", type=int, default=1 << 20, help="nominal particle count per GPU (dam-break)")
+    ap.add_argument("--particles", type=int, default=0,
+                    help="nominal particle count: per GPU (weak) or of the whole column (strong); "
+                         "default 1 M (N = 1, weak) / 4 M (strong, BASELINE.json configs[3])")
     ap.add_argument("--solver-iter", type=int, default=4)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N > 1: strong (default) = ONE dam-break column cut into N load-balanced x-slabs; "
+                         "weak = N mirrored 1 M columns side by side")
+    ap.add_argument("--settle-to", type=int, default=200,
+                    help="simulation frame at which the timed region starts when warmup is smaller (reference CLI "
+                         "warm-up default, args.hpp:36)")
     ap.add_argument("--fp64", action="store_true")
     ap.add_argument("--fast-math", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lds", action="store_true", help="A/B: per-particle global-memory gather kernels")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     dist = None
@@ -138,10 +232,16 @@ def main():
             local_rank = 0
             torch.cuda.set_device(0)
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"communicator has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    n_gpus = dist.get_world_size() if dist is not None else 1
 
     pkg = load_package()
-    flags = (0 if os.environ.get("PBF_BENCH_NO_EVENTS") else pkg.FLAG_STAGE_TIMING) | (pkg.FLAG_FAST_MATH if args.fast_math else 0) | (pkg.FLAG_NO_LDS if args.no_lds else 0)
-    scene, side = pkg.scene_dambreak(args.particles, args.fp64)
+    flags = (0 if os.environ.get("PBF_BENCH_NO_EVENTS") else pkg.FLAG_STAGE_TIMING) | \
+        (pkg.FLAG_FAST_MATH if args.fast_math else 0) | (pkg.FLAG_NO_LDS if args.no_lds else 0)
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    nominal = args.particles or ((1 << 22) if (scaling == "strong" and world > 1) else (1 << 20))
+    scene, side = pkg.scene_dambreak(nominal, args.fp64)
     n = len(scene["id"])
     p = pkg.default_params(args.solver_iter, side)
     drv = None
@@ -149,26 +249,43 @@ def main():
         solver = pkg.Solver(h=0.1, fp64=args.fp64, device=local_rank, flags=flags)
         solver.upload(**scene)
         run = lambda k: solver.steps(p, k)  # noqa: E731
+        total_particles = n
     else:
-        # Weak scaling: `world` dam-break columns side by side along x, one per rank, in ONE box of
-        # world*side x side x side; slabs of equal width, ghost-layer exchange over RCCL (slab.py).
         from pbf_sph_amd import slab
-        # Odd ranks hold the MIRROR image of the column (x -> side - x inside their sub-box): every cut plane is
-        # then a mirror plane of the whole set-up, i.e. dynamically a wall — each rank's problem is the N = 1
-        # dam-break, the net flux through a cut is zero and the load stays balanced (up to chaotic symmetry breaking).
-        x = scene["pos"][:, 0]
-        scene["pos"][:, 0] = (x.dtype.type(side) - x if rank % 2 else x) + x.dtype.type(rank * side)
-        scene["id"] += np.uint64(rank * n)
-        p.max_bound[0] = world * side
         stream = torch.cuda.Stream()
         torch.cuda.set_stream(stream)  # RCCL ops and the solver's kernels are ordered on this one stream
         solver = pkg.Solver(h=0.1, fp64=args.fp64, device=local_rank, flags=flags, stream=stream.cuda_stream)
-        cap = max(n // 2, 1 << 16)  # wire records per neighbour and phase
-        solver._chk(solver.L.pbf_reserve(solver.ctx, 3 * n + 2 * cap), "pbf_reserve")  # head-room if the load drifts
-        solver.upload(**scene)
+        if scaling == "weak":
+            # `world` dam-break columns side by side along x, one per rank, in ONE box of world*side x side x side;
+            # slabs of equal width.  Odd ranks hold the MIRROR image of the column (x -> side - x inside their
+            # sub-box): every cut plane is then a mirror plane of the whole set-up, i.e. dynamically a wall — each
+            # rank's problem is the N = 1 dam-break and the load stays balanced (up to chaotic symmetry breaking).
+            x = scene["pos"][:, 0]
+            scene["pos"][:, 0] = (x.dtype.type(side) - x if rank % 2 else x) + x.dtype.type(rank * side)
+            scene["id"] += np.uint64(rank * n)
+            p.max_bound[0] = world * side
+            cuts = slab.even_cuts(world, world * side)
+            mine = scene
+            total_particles = n * world
+            cap = max(n // 2, 1 << 16)  # wire records per neighbour and phase
+            reserve = 3 * n + 2 * cap
+            rebalance = 0
+        else:
+            # BASELINE.json configs[3]: ONE column (4 M nominal at N = 8) cut into `world` x-slabs holding equal
+            # particle counts (slab.balanced_cuts), re-cut as the column collapses (slab.SlabSolver.rebalance).
+            cuts = slab.balanced_cuts(world, scene["pos"][:, 0], side)
+            col = slab.columns_of(scene["pos"][:, 0])
+            sel = (col >= cuts[rank]) & (col < cuts[rank + 1])
+            mine = {k: v[sel] for k, v in scene.items()}
+            total_particles = n
+            cap = max(n // world // 2, 1 << 16)
+            reserve = 3 * (n // world) + 2 * cap
+            rebalance = 8
+        solver._chk(solver.L.pbf_reserve(solver.ctx, reserve), "pbf_reserve")  # head-room if the load drifts
+        solver.upload(**mine)
         eng = slab.HipEngine(solver, torch, torch.device("cuda", local_rank))
-        drv = slab.SlabSolver(eng, dist, rank, world, slab.even_cuts(world, world * side), cap,
-                              stage_via_host=(backend != "nccl"))
+        drv = slab.SlabSolver(eng, dist, rank, world, cuts, cap, stage_via_host=(backend != "nccl"),
+                              rebalance_every=rebalance)
         run = lambda k: drv.steps(p, k)  # noqa: E731
 
     def barrier():
@@ -177,130 +294,158 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # Warm-up; its last steps are bracketed stage by stage (HIP events on the solver's stream) to find the
-    # dominant stage and the per-stage split.  The timed region then brackets ONLY the dominant stage:
-    # 8 event records per step instead of 44 (the full set costs ~4 % at 1 M particles, ~10 % at 256 K).
-    split_steps = min(10, args.warmup)
+    # ---- settle + warm-up (untimed); a probe near their end finds the dominant kernel -----------------------
+    settle, first_timed = frame_plan(args.steps, args.warmup, args.settle_to)
+    pre = settle + args.warmup
+    probe = PROBE_STEPS if pre >= 4 * PROBE_STEPS else 0  # never probe in the first frames of the process
     solver.set_option("timing_mask", 0)
-    run(args.warmup - split_steps)
+    run(pre - probe)
     barrier()
-    solver.set_option("timing_mask", 0xFFFFFFFF)
+    names = list(solver.stage_times())
+    dom_name = None
+    if probe:
+        solver.set_option("timing_mask", 0xFFFFFFFF)
+        solver.reset_stage_times()
+        run(probe)
+        barrier()
+        pr = solver.stage_times()
+        composite = {k for k in pr if any(o.startswith(k + "/") and pr[o][1] > 0 for o in pr)}
+        dom_name = max((k for k in pr if k not in composite), key=lambda k: pr[k][0] * pr[k][1])
+    # timed region: only the dominant kernel is bracketed (HIP events on the solver's stream, 8 records per step
+    # instead of ~50); without a probe every stage is (costs ~4 % at 1 M)
+    solver.set_option("timing_mask", (1 << names.index(dom_name)) if dom_name else 0xFFFFFFFF)
     solver.reset_stage_times()
-    run(split_steps)
     barrier()
-    split = solver.stage_times()
-    names = list(split)
-    # an entry "stage/part" is one kernel inside "stage": the composite stage is then not a kernel of its own
-    composite = {k for k in split if any(o.startswith(k + "/") and split[o][1] > 0 for o in split)}
-    kernels = [k for k in split if k not in composite]
-    dom_name = max(kernels, key=lambda k: split[k][0] * split[k][1]) if split_steps else "sph-lambda"
-    solver.set_option("timing_mask", 1 << names.index(dom_name) if dom_name in names else 0xFFFFFFFF)
-    solver.reset_stage_times()
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    n_final = solver.n
+    stage = solver.stage_times()
+    n_final = solver.n if drv is None else eng.n_owned
+    imbalance = 1.0
     if dist is not None:
         t = torch.tensor([elapsed, float(n_final)], device="cuda", dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0].item())
-        assert int(round(float(t[1].item()))) == n * world, "particles were lost or duplicated across slabs"
-        imbalance = float(tmax[1].item()) / (n * 1.0)
-    stage = solver.stage_times()
+        assert int(round(float(t[1].item()))) == total_particles, "particles were lost or duplicated across slabs"
+        imbalance = float(tmax[1].item()) * world / total_particles
+    # ---- per-stage split: SPLIT_STEPS more frames, every stage bracketed (untimed) ---------------------------
+    solver.set_option("timing_mask", 0xFFFFFFFF)
+    solver.reset_stage_times()
+    run(SPLIT_STEPS)
+    barrier()
+    split = solver.stage_times()
+    if dom_name is None:
+        composite = {k for k in split if any(o.startswith(k + "/") and split[o][1] > 0 for o in split)}
+        dom_name = max((k for k in split if k not in composite), key=lambda k: split[k][0] * split[k][1])
 
     if rank == 0:
-        total_particles = n * world
         value = total_particles * args.steps / elapsed
+        n_rank = n if drv is None else total_particles / world
         sb = STAGE_BYTES_F64 if args.fp64 else STAGE_BYTES_F32
-        # dominant kernel = the kernel-level entry with the largest total time per step
-        per_step = {k: ms * calls / max(split_steps, 1) for k, (ms, calls) in split.items()}  # last warm-up steps
+        per_step = {k: ms * calls / SPLIT_STEPS for k, (ms, calls) in split.items()}
         dom = dom_name
-        dom_ms, dom_calls = stage[dom]  # the dominant stage: every launch of the timed region
+        dom_ms, dom_calls = stage[dom]  # the dominant kernel: every launch of the timed region
+        # neighbour-list statistics of the run's last build (always reported)
+        cnt = solver.nbr_counts()
+        overflow = float((cnt == 0xFFFFFFFF).mean()) if len(cnt) else 0.0
+        mean_list = float(np.minimum(cnt, 64).mean()) if len(cnt) else 0.0
+        S = 8 if args.fp64 else 4
         if dom == "sph-lambda/list-build":
-            # k_build_lists_q: own pStar + quantised position of every particle once + key in,
-            # list length + S list entries out per particle; S = mean length of the lists the last launch wrote
-            cnt = solver.nbr_counts()
-            mean_list = float(np.minimum(cnt, 64).mean())
-            dom_bytes = (32 if args.fp64 else 16) + 8 + 4 + 4 + 4 * mean_list
+            # the list build: own pStar + quantised position of every particle once + key in,
+            # list length + mean_list entries out per particle (the lists are this kernel's product)
+            dom_bytes = 4 * S + 8 + 4 + 4 + 4 * mean_list
+            dom_bytes_note = "16 (own pStar) + 8 (quantised positions, once) + 4 (key) in; 4 + 4*mean_list out"
+        elif dom == "sph-lambda/gather":
+            dom_bytes = sb["sph-lambda"]
+            dom_bytes_note = "SURVEY §8(d): lambda 12 R + 4 W per particle"
         else:
-            mean_list = None
             dom_bytes = sb[dom]
-        achieved = dom_bytes * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            dom_bytes_note = "SURVEY §8(d) per-stage figure"
+        achieved = dom_bytes * n_rank / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         bytes_step = (276 + 44 * args.solver_iter) if not args.fp64 else (528 + 88 * args.solver_iter)
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-        # WRITE_SIZE collected separately, 2 x FETCH gfx950 correction; profiles/r01_pmc_traffic.json) — only
-        # valid for the configuration those passes ran: 1 GPU, fp32, default particle count and math mode
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if world == 1 and not args.fp64 and args.particles == (1 << 20) and not args.fast_math and os.path.exists(tfile):
-            tag = {"sph-lambda/list-build": "k_build_lists", "sph-lambda": "LambdaOp", "sph-delta": "DeltaOp",
-                   "sph-diffuse": "DiffuseOp"}.get(dom)
+        # HBM bytes per launch of the dominant kernel: NOT measured in this run (PMC counters need rocprofv3) — read
+        # from the committed separate --pmc passes of this same command line (FETCH_SIZE and WRITE_SIZE collected
+        # separately, 2 x FETCH gfx950 correction) and only for the configuration those passes ran
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, TRAFFIC_FILE)
+        if world == 1 and not args.fp64 and nominal == (1 << 20) and not args.fast_math and os.path.exists(tfile):
+            kname = KERNEL_OF.get(dom, dom)
             for name, t in json.load(open(tfile)).items():
-                if tag and tag in name:
+                if kname.split("<")[0] in name and all(tok in name for tok in kname.replace(">", "").split("<")[1:]):
                     traffic = t["hbm_bytes_gfx950_corrected"]
+                    traffic_src = f"file: {TRAFFIC_FILE} (rocprofv3 --pmc passes of this command, not this run)"
         out = {
             "metric": "particle-steps/sec (1 M particles, 4 iters) + achieved HBM GB/s, 1/2/4/8 MI355X",
             "value": value,
             "unit": "particle-steps/s",
-            "n_gpus": world,
+            "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",  # per-GPU work is fixed: one 1 M-particle column per rank
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64" if args.fp64 else "f32",
             "data": "synthetic",
-            "config": {"workload": f"dam-break, {n} particles/GPU (nominal {args.particles}), box {side:.0f}^3, "
-                                   f"h=0.1, K={args.solver_iter}, dt=0.01245, scale=500",
+            "config": {"workload": f"dam-break, {total_particles} particles (nominal {nominal}"
+                                   f"{' per GPU' if (world > 1 and scaling == 'weak') else ''}), box {side:.0f}^3, "
+                                   f"h=0.1, K={args.solver_iter}, dt=0.01245, scale=500; timed = simulation frames "
+                                   f"[{first_timed}, {first_timed + args.steps}) after {settle} settle + "
+                                   f"{args.warmup} warm-up frames",
                        "particles": total_particles, "solver_iter": args.solver_iter,
+                       "settle_frames": settle, "first_timed_frame": first_timed,
                        "math": "fast (v_rsq, fma)" if args.fast_math else "precise (IEEE div/sqrt, no contraction)",
                        "parallelism": "1 GPU, device-resident" if world == 1 else
-                                      f"{world} x-slabs, one rank per GPU, 1-cell ghost layer refreshed after every "
-                                      f"lambda/delta launch over RCCL ({backend}); {world} columns side by side, odd ones mirrored; "
-                                      f"max rank load {imbalance:.2f}x mean"},
-            "roofline": {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stopwatch_entry": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_particle": dom_bytes, "mean_list_length": mean_list,
+                                      (f"{world} x-slabs, one rank per GPU, 1-cell ghost layer refreshed after every "
+                                       f"lambda/delta launch over RCCL ({backend}); " +
+                                       (f"{world} columns side by side, odd ones mirrored" if scaling == "weak" else
+                                        "ONE column, particle-balanced cuts, re-cut every 8 steps") +
+                                       f"; max rank load {imbalance:.2f}x mean")},
+            "roofline": {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stopwatch_entry": dom,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_particle": dom_bytes, "algorithmic_bytes_note": dom_bytes_note,
                          "mean_launch_ms": dom_ms, "launches_timed": dom_calls,
                          "whole_step_GBs": value * bytes_step / 1e9 / world,
-                         "note": "the neighbour kernels are instruction-issue / LDS / latency bound, not HBM-bound (SURVEY.md §8d)"},
+                         "whole_step_frac": value * bytes_step / 1e9 / world / HBM_PEAK_GBS,
+                         "note": "the neighbour kernels are instruction-issue / latency bound, not HBM-bound (SURVEY.md §8d)"},
+            "lists": {"mean_list_length": mean_list, "overflow_fraction": overflow},
             # the step's pure streams for contrast ("where >= 50 % of 8 TB/s is physically meaningful")
-            "roofline_streaming": {k: {"achieved": sb[k] * n / (split[k][0] * 1e-3) / 1e9, "unit": "GB/s",
-                                       "frac": sb[k] * n / (split[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline_streaming": {k: {"achieved": sb[k] * n_rank / (split[k][0] * 1e-3) / 1e9, "unit": "GB/s",
+                                       "frac": sb[k] * n_rank / (split[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        "algorithmic_bytes_per_particle": sb[k], "mean_launch_ms": split[k][0]}
                                    for k in ("sph-finalise", "advect+zindex") if k in split and split[k][0] > 0},
-            # the whole lambda stage (quantise + list build + list-driven lambda) against SURVEY.md §8d's 16 B/particle
-            "roofline_stage": {k: {"achieved": sb[k] * n / (split[k][0] * 1e-3) / 1e9, "unit": "GB/s",
-                                   "frac": sb[k] * n / (split[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            # the whole lambda / delta stages against SURVEY.md §8d's 16 / 28 B per particle
+            "roofline_stage": {k: {"achieved": sb[k] * n_rank / (split[k][0] * 1e-3) / 1e9, "unit": "GB/s",
+                                   "frac": sb[k] * n_rank / (split[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "algorithmic_bytes_per_particle": sb[k], "mean_stage_ms": split[k][0]}
                                for k in ("sph-lambda", "sph-delta") if k in split and split[k][0] > 0},
             "stage_ms_per_step": per_step,
-            "stage_split_from": f"last {split_steps} warm-up steps (all stages bracketed); roofline: timed region",
+            "stage_split_from": f"{SPLIT_STEPS} untimed frames after the timed region, every stage bracketed "
+                                f"(sum {sum(v for k, v in per_step.items() if '/' not in k):.3f} ms); roofline: every "
+                                f"launch of the timed region",
         }
         if world == 1:
             # SURVEY.md §8(d)'s secondary figure: C candidates per particle are distance-tested once per solver
-            # iteration (the list build); the S that survive get exact pair terms twice (lambda, delta-p)
+            # iteration (the list build); the mean_list that survive get exact pair terms twice (lambda, delta-p)
             try:
                 C = candidates_per_particle(solver.keys(), solver.table())
                 rate = value * args.solver_iter
                 out["pairs"] = {"candidates_per_particle": C, "candidate_tests_per_s": rate * C,
-                                "pair_terms_per_s": (rate * 2 * mean_list) if mean_list is not None else None}
+                                "pair_terms_per_s": rate * 2 * mean_list}
             except Exception as e:  # diagnostic only
                 out["pairs"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:
             state = solver.download()
-            cb, o = cpu_baseline(state, side, args.fp64, args.solver_iter)
+            cb, O = cpu_baseline(state, side, args.fp64, args.solver_iter)
             # the oracle is also the checker: one more GPU step from the same state must agree
             solver.step(p)
             g = solver.download()
             o2_state = None
             try:
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                import oracle_lib as O
                 # device_pow: the oracle evaluates pow(q,4) as (q*q)*(q*q) like the kernels => bit-exact expected
                 oo = O.Oracle(args.fp64, device_pow=not args.fast_math)
                 oo.set_particles(**state)
@@ -316,7 +461,7 @@ def main():
                 out["parity_check_bit_exact"] = bool(np.array_equal(g["pos"][gi], o2_state["pos"][wi]))
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

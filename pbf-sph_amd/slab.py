@@ -27,6 +27,11 @@ def column_of(x_world, scale=500.0, h=0.1, min_bound_x=0.0):
     return int((x_world / scale - (min_bound_x / scale - 2 * h)) / h)
 
 
+def columns_of(x_world, scale=500.0, h=0.1):
+    """Vectorised column_of for min_bound_x = 0 (every bench / test scene)."""
+    return ((np.asarray(x_world, np.float64) / scale + 2 * h) / h).astype(np.int64)
+
+
 def even_cuts(nranks, box_x, scale=500.0, h=0.1):
     """Equal-width slabs over [0, box_x]; the first / last slab also take the padding columns."""
     cols = [column_of(box_x * g / nranks, scale, h) for g in range(nranks + 1)]
@@ -36,8 +41,7 @@ def even_cuts(nranks, box_x, scale=500.0, h=0.1):
 
 def balanced_cuts(nranks, x_world_all, box_x, scale=500.0, h=0.1):
     """Cuts at particle-count quantiles of the column histogram (call with the gathered x of all ranks)."""
-    col = ((np.asarray(x_world_all, np.float64) / scale + 2 * h) / h).astype(np.int64)
-    order = np.sort(col)
+    order = np.sort(columns_of(x_world_all, scale, h))
     cuts = [0]
     for g in range(1, nranks):
         cuts.append(int(order[min(len(order) - 1, (len(order) * g) // nranks)]))
@@ -125,7 +129,7 @@ class SlabSolver:
     cuts   : nranks + 1 column boundaries, identical on every rank
     """
 
-    def __init__(self, engine, dist, rank, nranks, cuts, cap_records, stage_via_host=False):
+    def __init__(self, engine, dist, rank, nranks, cuts, cap_records, stage_via_host=False, rebalance_every=0):
         # stage_via_host: bounce the wire buffers through CPU tensors (lets several ranks share ONE GPU
         # under the "gloo" backend for tests; production uses "nccl" = RCCL straight from device memory)
         self.e, self.dist, self.rank, self.nranks = engine, dist, rank, nranks
@@ -139,7 +143,9 @@ class SlabSolver:
         self.cnt_recv = [engine.alloc(8) for _ in range(2)]
         self.sent = [0, 0]
         self.got = [0, 0]
-        self.stats = dict(migrated=0, ghosts=0, exchanges=0)
+        self.stats = dict(migrated=0, ghosts=0, exchanges=0, recuts=0)
+        self.rebalance_every = int(rebalance_every)
+        self.frame = 0
 
     def set_cuts(self, cuts):
         assert len(cuts) == self.nranks + 1

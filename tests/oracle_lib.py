@@ -55,59 +55,78 @@ def build(force=False):
 
 
 _lib = None
+_libs = {}
 _ref = None
+NATIVE_DIR = os.path.join(ORACLE_DIR, "_native")
 
 
 def _vp(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def lib():
+def build_native():
+    """The cpu_baseline builds BASELINE.md §4 promises: the same restatement at -O3 -march=native (no fast-math)
+    and at -Ofast -march=native (the reference's Release flags, CMakeLists.txt:136).  -march=native binds the
+    binary to the machine it was compiled on, so these are (re)built on the box that times them (make stamps the
+    CPU model).  Returns {"O3": path, "Ofast": path}; raises if the compiler is missing."""
+    subprocess.run(["make", "-C", ORACLE_DIR, "native"], check=True, capture_output=True)
+    return {k: os.path.join(NATIVE_DIR, f"libpbf_oracle_{k}.so") for k in ("O3", "Ofast")}
+
+
+def lib(path=None):
+    """path=None: the checker build (-O2, no fast-math, no contraction) every parity test uses."""
     global _lib
+    if path is not None:
+        if path not in _libs:
+            _libs[path] = _bind(C.CDLL(path))
+        return _libs[path]
     if _lib is None:
         build()
-        L = C.CDLL(ORACLE_SO)
-        L.pbf_oracle_create.restype = C.c_void_p
-        L.pbf_oracle_create.argtypes = [C.c_int]
-        L.pbf_oracle_destroy.argtypes = [C.c_void_p]
-        L.pbf_oracle_set_particles.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
-        L.pbf_oracle_count.restype = C.c_size_t
-        L.pbf_oracle_count.argtypes = [C.c_void_p]
-        L.pbf_oracle_get_particles.argtypes = [C.c_void_p] + [C.c_void_p] * 6
-        for name in ("step", "predict", "sort", "grid_table", "diffuse", "lambda", "delta", "finalise"):
-            f = getattr(L, "pbf_oracle_" + name)
-            f.argtypes = [C.c_void_p, C.POINTER(OracleParams)]
-            f.restype = C.c_int
-        for name in ("get_keys", "get_pstar", "get_lambda", "get_table"):
-            getattr(L, "pbf_oracle_" + name).argtypes = [C.c_void_p, C.c_void_p]
-        L.pbf_oracle_table_size.restype = C.c_size_t
-        L.pbf_oracle_table_size.argtypes = [C.c_void_p]
-        L.pbf_oracle_get_extent.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.pbf_oracle_candidate_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
-                                                 C.POINTER(C.c_double)]
-        L.pbf_oracle_morton_encode.restype = C.c_uint64
-        L.pbf_oracle_morton_encode.argtypes = [C.c_uint64] * 3
-        L.pbf_oracle_morton_decode.restype = C.c_uint64
-        L.pbf_oracle_morton_decode.argtypes = [C.c_uint64, C.c_int]
-        L.pbf_oracle_neighbour_codes.argtypes = [C.c_uint64, C.c_void_p]
-        L.pbf_oracle_poly6_factor.restype = C.c_double
-        L.pbf_oracle_poly6_factor.argtypes = [C.c_int, C.c_double]
-        L.pbf_oracle_spiky_factor.restype = C.c_double
-        L.pbf_oracle_spiky_factor.argtypes = [C.c_int, C.c_double]
-        L.pbf_oracle_scene_cubes.restype = C.c_size_t
-        L.pbf_oracle_scene_cubes.argtypes = [C.c_int, C.c_size_t] + [C.c_void_p] * 5
-        L.pbf_oracle_scene_dambreak.restype = C.c_size_t
-        L.pbf_oracle_scene_dambreak.argtypes = [C.c_int, C.c_size_t] + [C.c_void_p] * 5 + [C.POINTER(C.c_double)]
-        L.pbf_oracle_motion_offset.argtypes = [C.c_int, C.c_uint64, C.c_void_p]
-        L.pbf_oracle_set_pow4.argtypes = [C.c_void_p, C.c_int]
-        L.pbf_oracle_set_scratch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.pbf_oracle_surface.argtypes = [C.c_void_p, C.POINTER(OracleParams), C.POINTER(OracleMc), C.POINTER(C.c_uint64)]
-        L.pbf_oracle_surface_from_lattice.argtypes = [C.c_void_p, C.POINTER(OracleParams), C.POINTER(OracleMc), C.c_void_p,
-                                                      C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
-        L.pbf_oracle_get_lattice.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.pbf_oracle_get_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        _lib = L
+        _lib = _bind(C.CDLL(ORACLE_SO))
     return _lib
+
+
+def _bind(L):
+    L.pbf_oracle_create.restype = C.c_void_p
+    L.pbf_oracle_create.argtypes = [C.c_int]
+    L.pbf_oracle_destroy.argtypes = [C.c_void_p]
+    L.pbf_oracle_set_particles.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
+    L.pbf_oracle_count.restype = C.c_size_t
+    L.pbf_oracle_count.argtypes = [C.c_void_p]
+    L.pbf_oracle_get_particles.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    for name in ("step", "predict", "sort", "grid_table", "diffuse", "lambda", "delta", "finalise"):
+        f = getattr(L, "pbf_oracle_" + name)
+        f.argtypes = [C.c_void_p, C.POINTER(OracleParams)]
+        f.restype = C.c_int
+    for name in ("get_keys", "get_pstar", "get_lambda", "get_table"):
+        getattr(L, "pbf_oracle_" + name).argtypes = [C.c_void_p, C.c_void_p]
+    L.pbf_oracle_table_size.restype = C.c_size_t
+    L.pbf_oracle_table_size.argtypes = [C.c_void_p]
+    L.pbf_oracle_get_extent.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pbf_oracle_candidate_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                             C.POINTER(C.c_double)]
+    L.pbf_oracle_morton_encode.restype = C.c_uint64
+    L.pbf_oracle_morton_encode.argtypes = [C.c_uint64] * 3
+    L.pbf_oracle_morton_decode.restype = C.c_uint64
+    L.pbf_oracle_morton_decode.argtypes = [C.c_uint64, C.c_int]
+    L.pbf_oracle_neighbour_codes.argtypes = [C.c_uint64, C.c_void_p]
+    L.pbf_oracle_poly6_factor.restype = C.c_double
+    L.pbf_oracle_poly6_factor.argtypes = [C.c_int, C.c_double]
+    L.pbf_oracle_spiky_factor.restype = C.c_double
+    L.pbf_oracle_spiky_factor.argtypes = [C.c_int, C.c_double]
+    L.pbf_oracle_scene_cubes.restype = C.c_size_t
+    L.pbf_oracle_scene_cubes.argtypes = [C.c_int, C.c_size_t] + [C.c_void_p] * 5
+    L.pbf_oracle_scene_dambreak.restype = C.c_size_t
+    L.pbf_oracle_scene_dambreak.argtypes = [C.c_int, C.c_size_t] + [C.c_void_p] * 5 + [C.POINTER(C.c_double)]
+    L.pbf_oracle_motion_offset.argtypes = [C.c_int, C.c_uint64, C.c_void_p]
+    L.pbf_oracle_set_pow4.argtypes = [C.c_void_p, C.c_int]
+    L.pbf_oracle_set_scratch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pbf_oracle_surface.argtypes = [C.c_void_p, C.POINTER(OracleParams), C.POINTER(OracleMc), C.POINTER(C.c_uint64)]
+    L.pbf_oracle_surface_from_lattice.argtypes = [C.c_void_p, C.POINTER(OracleParams), C.POINTER(OracleMc), C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.pbf_oracle_get_lattice.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pbf_oracle_get_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return L
 
 
 def ref():
@@ -170,12 +189,13 @@ def make_params(h=0.1, dt=0.0083 * 1.5, scale=500.0, iteration=4, force=(0.0, 9.
 class Oracle:
     """Stateful CPU oracle (one per precision)."""
 
-    def __init__(self, fp64=False, device_pow=False):
+    def __init__(self, fp64=False, device_pow=False, so_path=None):
         """device_pow=True evaluates pow(q, 4) as (q*q)*(q*q) like the HIP kernels do — the ONE
-        arithmetic substitution of the device path; default False = std::pow as in ompsph.hpp:240."""
+        arithmetic substitution of the device path; default False = std::pow as in ompsph.hpp:240.
+        so_path: another build of the same source (build_native(): timing only, never a checker)."""
         self.fp64 = bool(fp64)
         self.dtype = np.float64 if fp64 else np.float32
-        self.L = lib()
+        self.L = lib(so_path)
         self.h = C.c_void_p(self.L.pbf_oracle_create(int(self.fp64)))
         if device_pow:
             self.L.pbf_oracle_set_pow4(self.h, 1)
