@@ -204,6 +204,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
+    # stdout carries the ONE JSON line and nothing else: whatever libraries print to fd 1 while the run lasts
+    # (RCCL's version banner, gloo's connection notes) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
 
@@ -252,9 +257,10 @@ def main():
         total_particles = n
     else:
         from pbf_sph_amd import slab
-        stream = torch.cuda.Stream()
-        torch.cuda.set_stream(stream)  # RCCL ops and the solver's kernels are ordered on this one stream
-        solver = pkg.Solver(h=0.1, fp64=args.fp64, device=local_rank, flags=flags, stream=stream.cuda_stream)
+        # the whole slab step — kernels AND exchanges — runs inside libpbf_hip.so (pbf_slab_step): RCCL send/recv over
+        # xGMI on the solver's stream.  PBF_BENCH_BACKEND=gloo: rehearsal with several ranks sharing one GPU
+        # (host-callback transport).
+        solver = pkg.Solver(h=0.1, fp64=args.fp64, device=local_rank, flags=flags)
         if scaling == "weak":
             # `world` dam-break columns side by side along x, one per rank, in ONE box of world*side x side x side;
             # slabs of equal width.  Odd ranks hold the MIRROR image of the column (x -> side - x inside their
@@ -267,25 +273,25 @@ def main():
             cuts = slab.even_cuts(world, world * side)
             mine = scene
             total_particles = n * world
-            cap = max(n // 2, 1 << 16)  # wire records per neighbour and phase
-            reserve = 3 * n + 2 * cap
+            per_rank = n
             rebalance = 0
         else:
             # BASELINE.json configs[3]: ONE column (4 M nominal at N = 8) cut into `world` x-slabs holding equal
-            # particle counts (slab.balanced_cuts), re-cut as the column collapses (slab.SlabSolver.rebalance).
+            # particle counts (slab.balanced_cuts), re-cut every 8 steps as the column collapses (slab.recut).
             cuts = slab.balanced_cuts(world, scene["pos"][:, 0], side)
             col = slab.columns_of(scene["pos"][:, 0])
             sel = (col >= cuts[rank]) & (col < cuts[rank + 1])
             mine = {k: v[sel] for k, v in scene.items()}
             total_particles = n
-            cap = max(n // world // 2, 1 << 16)
-            reserve = 3 * (n // world) + 2 * cap
+            per_rank = max(1, n // world)
             rebalance = 8
-        solver._chk(solver.L.pbf_reserve(solver.ctx, reserve), "pbf_reserve")  # head-room if the load drifts
+        cap_ghost = max(per_rank // 4, 1 << 15)  # wire records per neighbour: copies of one boundary column
+        cap_mig = max(per_rank // 16, 1 << 13)   # particles crossing a cut in one step
+        solver._chk(solver.L.pbf_reserve(solver.ctx, 3 * per_rank + 2 * cap_ghost), "pbf_reserve")  # head-room if the load drifts
         solver.upload(**mine)
-        eng = slab.HipEngine(solver, torch, torch.device("cuda", local_rank))
-        drv = slab.SlabSolver(eng, dist, rank, world, cuts, cap, stage_via_host=(backend != "nccl"),
-                              rebalance_every=rebalance)
+        drv = slab.CSlabSolver(solver, dist, torch, rank, world, cuts, cap_mig, cap_ghost,
+                               transport="rccl" if backend == "nccl" else "gloo-host", rebalance_every=rebalance,
+                               device=local_rank)
         run = lambda k: drv.steps(p, k)  # noqa: E731
 
     def barrier():
@@ -321,7 +327,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     stage = solver.stage_times()
-    n_final = solver.n if drv is None else eng.n_owned
+    n_final = solver.n if drv is None else drv.n_owned
     imbalance = 1.0
     if dist is not None:
         t = torch.tensor([elapsed, float(n_final)], device="cuda", dtype=torch.float64)
@@ -400,7 +406,9 @@ def main():
                        "math": "fast (v_rsq, fma)" if args.fast_math else "precise (IEEE div/sqrt, no contraction)",
                        "parallelism": "1 GPU, device-resident" if world == 1 else
                                       (f"{world} x-slabs, one rank per GPU, 1-cell ghost layer refreshed after every "
-                                       f"lambda/delta launch over RCCL ({backend}); " +
+                                       f"lambda/delta launch: pbf_slab_step inside the library, " +
+                                       ("ncclSend/ncclRecv over xGMI" if backend == "nccl" else "host-callback transport (gloo rehearsal)") +
+                                       f", {drv.rounds // max(1, drv.frame)} exchange rounds per step; " +
                                        (f"{world} columns side by side, odd ones mirrored" if scaling == "weak" else
                                         "ONE column, particle-balanced cuts, re-cut every 8 steps") +
                                        f"; max rank load {imbalance:.2f}x mean")},
@@ -461,7 +469,7 @@ def main():
                 out["parity_check_bit_exact"] = bool(np.array_equal(g["pos"][gi], o2_state["pos"][wi]))
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

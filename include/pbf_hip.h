@@ -93,7 +93,10 @@ int pbf_download(pbf_ctx *ctx, uint64_t *id, uint8_t *type, void *mass, void *po
 size_t pbf_count(const pbf_ctx *ctx);
 
 /* AoS path for the C++ shim: `particles` is the caller's std::vector<Particle>::data()
- * (src/sph.hpp:36-54).  Unpacked / repacked on the device; offsets in bytes. */
+ * (src/sph.hpp:36-54).  Unpacked / repacked on the device; offsets in bytes.  The buffer is page-locked in place
+ * (hipHostRegister, kept while the same pointer comes back: benchmark.cpp:33,47 passes one vector every frame) so both
+ * copies are plain DMA.  pbf_download_aos writes the FIELDS; struct padding bytes (no part of the reference's contract:
+ * its write-back copies whole structs, ompsph.hpp:479-481) receive the bytes the last uploaded image held at that slot. */
 typedef struct pbf_aos_layout {
   uint32_t stride, off_id, off_type, off_mass, off_pos, off_vel, off_colour;
 } pbf_aos_layout;
@@ -188,6 +191,44 @@ int pbf_slab_pack(pbf_ctx *ctx, void *send_left, void *send_right);
 int pbf_slab_unpack(pbf_ctx *ctx, const void *recv_left, const void *recv_right);
 int pbf_slab_finish(pbf_ctx *ctx); /* after finalise: drop the copies */
 size_t pbf_owned_count(const pbf_ctx *ctx);
+/* load balance: owned particles per GLOBAL grid column (keys of the last pbf_stage_predict), 1024 bins; synchronises.
+ * The driver all-reduces the histograms and moves the cuts (pbf-sph_amd/slab.py recut()). */
+int pbf_slab_column_histogram(pbf_ctx *ctx, uint32_t out[1024]);
+
+/* ---- communicator + whole slab step behind the C ABI ------------------------------------------------------
+ * (no reference counterpart).  A pbf_comm links this rank with its left (rank - 1) and right (rank + 1) slab:
+ *   RCCL over xGMI  pbf_comm_unique_id on rank 0, the 128 bytes are broadcast by the caller over any channel, then
+ *                   pbf_comm_create_rccl on every rank = ncclCommInitRank; the exchanges are
+ *                   ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the solver's stream (no host sync);
+ *   host callback   bring-up and tests (several ranks sharing ONE GPU under gloo): the library stages the wire
+ *                   buffers through pinned host memory and calls `fn` to move the bytes (return 0 = ok).
+ * pbf_slab_attach hands the communicator, the cuts (nranks + 1 column boundaries, identical on every rank) and the
+ * wire capacities to the ctx; pbf_slab_step then runs ONE step including every exchange:
+ *   predict -> [migrants] -> [ghost copies] -> sort -> diffuse -> K x { lambda -> [field] -> delta -> [field] }
+ *   -> finalise                ([..] = one exchange round: 2 + 2K rounds per step)
+ * The two assembly rounds carry their record counts in a header of a capacity-sized message (no count round trip);
+ * the host reads those counts once per assembly round (2 small synchronising read-backs per step), the 2K field
+ * rounds need none.  A record count beyond the capacity is an error (PBF_ERR_COMM), never silent loss. */
+typedef struct pbf_comm pbf_comm;
+#define PBF_COMM_ID_BYTES 128
+typedef int (*pbf_exchange_fn)(void *user, const void *send_left, size_t send_left_bytes, const void *send_right,
+                               size_t send_right_bytes, void *recv_left, size_t recv_left_bytes, void *recv_right,
+                               size_t recv_right_bytes); /* host pointers */
+int pbf_comm_unique_id(void *id128);
+int pbf_comm_create_rccl(const void *id128, int nranks, int rank, int device, pbf_comm **out);
+int pbf_comm_create_host_callback(pbf_exchange_fn fn, void *user, int nranks, int rank, pbf_comm **out);
+void pbf_comm_destroy(pbf_comm *comm);
+const char *pbf_comm_last_error(const pbf_comm *comm); /* comm may be NULL: last failed create on this thread */
+uint64_t pbf_comm_rounds(const pbf_comm *comm);        /* exchange rounds so far */
+/* in-place sum over all ranks of `count` uint32 in DEVICE memory (load balance: column histograms); RCCL
+ * communicators only (a host-callback communicator returns PBF_ERR_COMM: its caller reduces on the host) */
+int pbf_comm_allreduce_u32(pbf_comm *comm, void *device_u32, size_t count, void *stream);
+/* cuts[nranks + 1]; cap_migrants / cap_ghosts = wire capacity in records per neighbour.  The ctx keeps the pointer
+ * to comm (not owned).  Switches the ctx to the rank-local key frame (pbf_slab_configure). */
+int pbf_slab_attach(pbf_ctx *ctx, pbf_comm *comm, const uint32_t *cuts, uint32_t cap_migrants, uint32_t cap_ghosts);
+int pbf_slab_set_cuts(pbf_ctx *ctx, const uint32_t *cuts); /* load balance: new cuts (same on every rank) */
+int pbf_slab_step(pbf_ctx *ctx, const pbf_params *params);
+int pbf_slab_steps(pbf_ctx *ctx, const pbf_params *params, uint32_t count);
 
 /* ---- scene factory (sph.hpp:127-186; dam-break: SURVEY.md §8d) — host only, no GPU needed -- */
 size_t pbf_scene_cubes(int fp64, size_t count, uint64_t *id, uint8_t *type, void *mass, void *pos, void *vel,

@@ -27,6 +27,7 @@
 #include <string>
 #include <vector>
 
+#include <thread>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -154,11 +155,23 @@ template <typename N> struct Oracle final : pbf_oracle {
 
   template <typename F> void foreach_1d(int threads, size_t size, const F &f) const {
     // ompsph.hpp:39-44
+#if defined(PBF_ORACLE_STD_THREADS)
+    // ThreadSanitizer build (oracle/Makefile `san`): the same static partition on std::thread — libgomp's barriers are
+    // invisible to TSan (every parallel-for would be reported), pthread create / join are not.
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(threads > 0 ? size_t(threads) : 4, size));
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nt; ++t)
+      pool.emplace_back([&, t] {
+        for (size_t i = size * t / nt; i < size * (t + 1) / nt; ++i) f(i);
+      });
+    for (auto &th : pool) th.join();
+#else
 #ifdef _OPENMP
     const int nt = threads > 0 ? threads : omp_get_max_threads();
 #pragma omp parallel for num_threads(nt) schedule(static)
 #endif
     for (long i = 0; i < static_cast<long>(size); ++i) f(static_cast<size_t>(i));
+#endif
   }
 
   // sph.hpp:203-213 — walk the 27 ranges; last table entry yields an empty range

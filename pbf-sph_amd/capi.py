@@ -6,7 +6,8 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libpbf_hip.so")
+# PBF_HIP_LIB: A/B another build of the same sources (diagnostic; tools/ab_flags.sh)
+LIB_PATH = os.environ.get("PBF_HIP_LIB") or os.path.join(PKG_DIR, "libpbf_hip.so")
 
 ABI_VERSION = 1
 FLAG_STAGE_TIMING = 1 << 0
@@ -77,6 +78,10 @@ class SlabCut(C.Structure):
     _fields_ = [("xlo", C.c_uint32), ("xhi", C.c_uint32), ("has_left", C.c_int32), ("has_right", C.c_int32)]
 
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                          C.c_void_p, C.c_size_t)
+
+
 class AosLayout(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("stride", "off_id", "off_type", "off_mass", "off_pos", "off_vel",
                                           "off_colour")]
@@ -133,6 +138,18 @@ _SIGS = {
     "pbf_slab_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pbf_slab_finish": (C.c_int, [C.c_void_p]),
     "pbf_owned_count": (C.c_size_t, [C.c_void_p]),
+    "pbf_slab_column_histogram": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pbf_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pbf_comm_create_rccl": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "pbf_comm_create_host_callback": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "pbf_comm_destroy": (None, [C.c_void_p]),
+    "pbf_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "pbf_comm_rounds": (C.c_uint64, [C.c_void_p]),
+    "pbf_comm_allreduce_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pbf_slab_attach": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "pbf_slab_set_cuts": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pbf_slab_step": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
+    "pbf_slab_steps": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_uint32]),
     "pbf_scene_cubes": (C.c_size_t, [C.c_int, C.c_size_t] + [C.c_void_p] * 6),
     "pbf_scene_dambreak": (C.c_size_t, [C.c_int, C.c_size_t] + [C.c_void_p] * 6 + [C.POINTER(C.c_double)]),
     "pbf_apply_motion": (None, [C.c_int, C.POINTER(Params), C.c_uint64, C.POINTER(Params)]),

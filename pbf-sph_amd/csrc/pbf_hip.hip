@@ -17,6 +17,7 @@
 #include "pbf_kernels.hpp"
 #include "pbf_slab.hpp"
 #include "pbf_mc.hpp"
+#include "pbf_comm.hpp"
 
 using namespace pbf;
 
@@ -67,12 +68,18 @@ struct pbf_ctx {
   DevBuf pstar[3];       // [0],[1]: sort ping-pong partner of set 0/1 ; [2]: Jacobi partner
   DevBuf count, table, blockSums, permTmp, wells, staging;
   // slab decomposition (pbf_slab_*): bookkeeping of what was sent / received this step
-  DevBuf slotOf, selCounts, selTotals, ghostSrcL, ghostSrcR;
+  DevBuf slotOf, selCounts, selTotals, ghostSrcL, ghostSrcR, colHist;
   bool slabActive = false, realObstacles = false;
   bool slabConfigured = false;  // pbf_slab_configure: rank-local x frame for the keys (compact table per rank)
   pbf_slab_cut slabCut{0, 0, 0, 0};
   uint32_t xoff = 0;
   int32_t shiftL = 0, shiftR = 0;
+  // pbf_slab_attach: the whole step incl. the exchanges runs inside the library (pbf_slab_step)
+  pbf_comm *comm = nullptr;  // not owned
+  std::vector<uint32_t> cuts;
+  uint32_t capMig = 0, capGhost = 0;
+  DevBuf wireSend[2], wireRecv[2];
+  uint32_t *hostCounts = nullptr;  // pinned: read-back of the assembly rounds' counts
   size_t reserve = 0;        // pbf_reserve: capacity kept for migrants and ghost copies
   uint32_t nOwned = 0, sentL = 0, sentR = 0, gotL = 0, gotR = 0;
   // marching cubes (pbf_surface)
@@ -82,6 +89,14 @@ struct pbf_ctx {
   DevBuf qpos;               // 8-byte quantised pStar for the list build (k_build_lists_q)
   DevBuf nbrList, nbrCount;  // neighbour lists handed from the lambda launch to the delta launch (NBR_CAP per particle)
   bool nbrValid = false;     // the lists describe pstar[pcur] as it is now
+  // advance() path: the caller's std::vector<Particle> buffer, page-locked in place (hipHostRegister) so the per-frame
+  // 56-byte-per-particle upload and download are plain DMA instead of the runtime's pageable staging
+  void *regPtr = nullptr;
+  size_t regBytes = 0;
+  size_t stagedBytes = 0;  // bytes of `staging` that hold a defined AoS image (padding bytes of a download come from it)
+  pbf_params lastParams{};   // the params of the last stage call (entry points without a params argument derive their consts from it)
+  bool haveParams = false;
+  bool qposValid = false;    // qpos is the quantised copy of pstar[pcur] (written by the sort, delta-p and the slab refresh)
   bool reuseLists = true;    // option "reuse_lists"
   // option "split_build": 0 = lambda builds the neighbour lists while it gathers (k_gather_lists<SAVE>);
   // otherwise the build is a launch of its own followed by a list-driven lambda: 1 = k_gather_lists build-only,
@@ -91,7 +106,8 @@ struct pbf_ctx {
   bool fuseDiffuse = false;  // option "fuse_diffuse": pbf_step folds the diffuse walk into the first lambda launch
                              // (bit-identical; measured 2 % SLOWER at 1 M — the colour loads stall the filter loop — so off)
   bool fuseDiffuseNow = false;
-  DevBuf bricks, brickCtl;  // non-empty brick list; brickCtl = {nActive, ticket[kTickets]}
+  DevBuf bricks, brickCtl;  // non-empty brick list; brickCtl = {nActive, ticket[kTickets], nBigCells}
+  DevBuf bigCells;          // cells with more than BIG_CELL members this step (k_sort_big_cells)
   uint32_t gatherSeq = 0;   // which ticket word the next persistent gather launch uses
   int numCUs = 256;
   uint32_t timingMask = 0xFFFFFFFFu;  // option "timing_mask": which stages PBF_FLAG_STAGE_TIMING brackets with events
@@ -253,7 +269,7 @@ int ensure_table(pbf_ctx *ctx, uint32_t tableN) {
   const size_t nb = (entries + SCAN_TILE - 1) / SCAN_TILE + 1;
   if (int rc = ensure(ctx, ctx->blockSums, nb * 4)) return rc;
   if (int rc = ensure(ctx, ctx->bricks, (entries / Brick<kBrickZ>::HOME + 2) * 4)) return rc;
-  if (int rc = ensure(ctx, ctx->brickCtl, (kTickets + 1) * 4)) return rc;
+  if (int rc = ensure(ctx, ctx->brickCtl, (kTickets + 2) * 4)) return rc;
   ctx->tableCap = ctx->count.cap / 4 - SCAN_TILE;
   return PBF_OK;
 }
@@ -302,7 +318,8 @@ struct StageTimer {
   }
 };
 
-inline dim3 grid_for(size_t n) { return dim3(unsigned((n + BLOCK - 1) / BLOCK)); }
+// (at least one workgroup: a slab may own no particle at all, and every kernel bounds-checks its index)
+inline dim3 grid_for(size_t n) { return dim3(unsigned(std::max<size_t>(1, (n + BLOCK - 1) / BLOCK))); }
 
 #define LAUNCH_CHECK(ctx)                                                  \
   do {                                                                     \
@@ -347,6 +364,7 @@ template <typename N> int stage_predict(pbf_ctx *ctx, const pbf_params *p) {
   ctx->pcur = s;
   ctx->sorted = false;
   ctx->nbrValid = false;
+  ctx->qposValid = false;
   ctx->counted = true;
   ctx->countedTableN = c.tableN;
   return PBF_OK;
@@ -367,14 +385,22 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLOCK), 0, ctx->stream, sums, nb);
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(BLOCK), 0, ctx->stream, count, len, sums, table);
   const int s = ctx->cur, d = 1 - s;
+  // brickCtl = {nActive bricks, tickets[kTickets], number of big cells}: zeroed once per step
+  HIPCHK(ctx, hipMemsetAsync(ctx->brickCtl.p, 0, (kTickets + 2) * 4, ctx->stream));
+  uint32_t *nBig = ctx->brickCtl.as<uint32_t>() + kTickets + 1;
+  if (int rc = ensure(ctx, ctx->bigCells, (ctx->cap / BIG_CELL + 2) * 4)) return rc;
   hipLaunchKernelGGL(k_scatter_slots, grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c.n, c.tableN,
-                     ctx->key[s].as<const uint32_t>(), table, count, ctx->permTmp.as<uint32_t>());
-  hipLaunchKernelGGL((k_rank_move<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c.n, c.tableN,
+                     ctx->key[s].as<const uint32_t>(), table, count, ctx->permTmp.as<uint32_t>(),
+                     ctx->bigCells.as<uint32_t>(), nBig);
+  // pile-ups only: cells with more than BIG_CELL members get their segment sorted (exits at once when there are none)
+  hipLaunchKernelGGL(k_sort_big_cells, dim3(64), dim3(BLOCK), 0, ctx->stream, table, c.tableN,
+                     ctx->bigCells.as<const uint32_t>(), nBig, ctx->permTmp.as<uint32_t>(),
+                     ctx->key[s].as<const uint32_t>());
+  hipLaunchKernelGGL((k_rank_move<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, c.n, c.tableN,
                      ctx->permTmp.as<const uint32_t>(), table, arrays<N>(ctx, s, s), arrays<N>(ctx, d, d),
-                     ctx->slabActive ? ctx->slotOf.as<uint32_t>() : nullptr);
+                     ctx->slabActive ? ctx->slotOf.as<uint32_t>() : nullptr, ctx->qpos.as<uint2>());
   {  // list of non-empty bricks for the persistent gather kernels (+ fresh tickets)
     const uint32_t home = Brick<kBrickZ>::HOME, nBricks = (c.tableN + home - 1) / home;
-    HIPCHK(ctx, hipMemsetAsync(ctx->brickCtl.p, 0, (kTickets + 1) * 4, ctx->stream));
     hipLaunchKernelGGL(k_brick_list, grid_for(nBricks), dim3(BLOCK), 0, ctx->stream, table, c.tableN, home, nBricks,
                        ctx->bricks.as<uint32_t>(), ctx->brickCtl.as<uint32_t>());
     ctx->gatherSeq = 0;
@@ -384,6 +410,7 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
   ctx->pcur = d;
   ctx->sorted = true;
   ctx->nbrValid = false;
+  ctx->qposValid = true;
   ctx->counted = false;
   return PBF_OK;
 }
@@ -420,7 +447,10 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
       else if constexpr (Op::kTileable && Op::kFilter) {  // (the ops that filter on pStar itself: lambda, delta-p)
         if (ctx->splitBuild >= 4) {
           uint2 *qp = ctx->qpos.as<uint2>();
-          hipLaunchKernelGGL((k_quantise<N>), g, b, 0, ctx->stream, c, Op::src(args), qp);
+          if (!ctx->qposValid) {  // (only after a stage that moved pStar without refreshing its quantised copy)
+            hipLaunchKernelGGL((k_quantise<N>), g, b, 0, ctx->stream, c, Op::src(args), qp);
+            ctx->qposValid = true;
+          }
           StageTimer tb(ctx, ST_BUILD);
           if (ctx->splitBuild == 4)
             hipLaunchKernelGGL((k_build_lists_q<N, 2>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc);
@@ -560,13 +590,15 @@ template <typename N> int stage_delta(pbf_ctx *ctx, const pbf_params *p) {
   const GatherMode from = ctx->nbrValid ? GATHER_FROM_LISTS : GATHER_PLAIN;
   ctx->nbrValid = false;  // delta moves pStar: the lists are stale afterwards
   int rc;
+  // delta-p's epilogue also writes the quantised copy of the new pStar: the next iteration's list build needs it
+  uint2 *qp = ctx->qposValid ? ctx->qpos.as<uint2>() : nullptr;
   if (ctx->fast) {
     typename DeltaOp<N, true>::Args args{ctx->pstar[in].as<const vec4<N>>(), ctx->pstar[out].as<vec4<N>>(),
-                                         ctx->type[s].as<const uint8_t>()};
+                                         ctx->type[s].as<const uint8_t>(), qp};
     rc = launch_gather<N, DeltaOp<N, true>>(ctx, c, args, from);
   } else {
     typename DeltaOp<N, false>::Args args{ctx->pstar[in].as<const vec4<N>>(), ctx->pstar[out].as<vec4<N>>(),
-                                          ctx->type[s].as<const uint8_t>()};
+                                          ctx->type[s].as<const uint8_t>(), qp};
     rc = launch_gather<N, DeltaOp<N, false>>(ctx, c, args, from);
   }
   if (rc) return rc;
@@ -642,6 +674,8 @@ int check(pbf_ctx *ctx, const pbf_params *p, bool needSorted) {
   if (!(p->scale > 0) || !(p->dt > 0)) return fail(ctx, PBF_ERR_INVALID, "dt and scale must be > 0");
   if (needSorted && !ctx->sorted) return fail(ctx, PBF_ERR_STATE, "stage needs pbf_stage_sort first");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->lastParams = *p;
+  ctx->haveParams = true;
   return PBF_OK;
 }
 
@@ -799,11 +833,13 @@ void pbf_destroy(pbf_ctx *ctx) {
   DevBuf *all[] = {&ctx->pos4[0], &ctx->pos4[1], &ctx->vel4[0], &ctx->vel4[1], &ctx->col4[0],  &ctx->col4[1],
                    &ctx->id[0],   &ctx->id[1],   &ctx->type[0], &ctx->type[1], &ctx->key[0],   &ctx->key[1],
                    &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2], &ctx->count, &ctx->table,   &ctx->blockSums,
-                   &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl,
+                   &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl, &ctx->bigCells,
                    &ctx->latticePN, &ctx->latticeC, &ctx->mcCounts, &ctx->mcOffsets, &ctx->mcSums, &ctx->meshV, &ctx->meshN,
-                   &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR};
+                   &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR, &ctx->colHist, &ctx->wireSend[0], &ctx->wireSend[1], &ctx->wireRecv[0], &ctx->wireRecv[1]};
   for (DevBuf *b : all)
     if (b->p) (void)hipFree(b->p);
+  if (ctx->hostCounts) (void)hipHostFree(ctx->hostCounts);
+  if (ctx->regPtr) (void)hipHostUnregister(ctx->regPtr);
   if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -833,6 +869,24 @@ int pbf_download(pbf_ctx *ctx, uint64_t *id, uint8_t *type, void *mass, void *po
 
 size_t pbf_count(const pbf_ctx *ctx) { return ctx ? ctx->n : 0; }
 
+namespace {
+// Page-lock the caller's AoS buffer once and keep the registration while the same buffer comes back every frame
+// (benchmark.cpp:33,47 calls advance() on one vector).  Failure is not an error: the copy then takes the pageable path.
+void pin_user_buffer(pbf_ctx *ctx, const void *ptr, size_t bytes) {
+  if (ctx->regPtr == ptr && ctx->regBytes >= bytes) return;
+  if (ctx->regPtr) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipHostUnregister(ctx->regPtr);
+    ctx->regPtr = nullptr, ctx->regBytes = 0;
+  }
+  if (bytes < (1u << 20)) return;  // small scenes: registration costs more than it saves
+  if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) == hipSuccess)
+    ctx->regPtr = const_cast<void *>(ptr), ctx->regBytes = bytes;
+  else
+    (void)hipGetLastError();
+}
+}  // namespace
+
 int pbf_upload_aos(pbf_ctx *ctx, size_t n, const void *particles, const pbf_aos_layout *l) {
   if (!ctx) return PBF_ERR_INVALID;
   if (!l || (n && !particles)) return fail(ctx, PBF_ERR_INVALID, "NULL argument");
@@ -850,7 +904,9 @@ int pbf_upload_aos(pbf_ctx *ctx, size_t n, const void *particles, const pbf_aos_
       break;
     }
   if (int rc = ensure(ctx, ctx->staging, n * l->stride)) return rc;
+  pin_user_buffer(ctx, particles, n * l->stride);
   HIPCHK(ctx, hipMemcpyAsync(ctx->staging.p, particles, n * l->stride, hipMemcpyHostToDevice, ctx->stream));
+  ctx->stagedBytes = n * l->stride;
   AosLayout L{l->stride, l->off_id, l->off_type, l->off_mass, l->off_pos, l->off_vel, l->off_colour};
   if (ctx->fp64)
     hipLaunchKernelGGL((k_unpack_aos<double>), grid_for(n), dim3(BLOCK), 0, ctx->stream, uint32_t(n),
@@ -859,6 +915,9 @@ int pbf_upload_aos(pbf_ctx *ctx, size_t n, const void *particles, const pbf_aos_
     hipLaunchKernelGGL((k_unpack_aos<float>), grid_for(n), dim3(BLOCK), 0, ctx->stream, uint32_t(n),
                        ctx->staging.as<const uint8_t>(), L, arrays<float>(ctx, 0, 0));
   LAUNCH_CHECK(ctx);
+  // the caller owns `particles` and may change or free it as soon as we return: from page-locked memory the copy
+  // above is a genuinely asynchronous DMA, so wait for it (the pageable path used to block inside the runtime)
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return PBF_OK;
 }
 
@@ -868,9 +927,18 @@ int pbf_download_aos(pbf_ctx *ctx, void *particles, const pbf_aos_layout *l) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t n = ctx->n;
   if (n == 0) return PBF_OK;
+  const size_t before = ctx->staging.cap;
   if (int rc = ensure(ctx, ctx->staging, n * l->stride)) return rc;
-  // padding bytes of the caller's structs are preserved: start from the host image
-  HIPCHK(ctx, hipMemcpyAsync(ctx->staging.p, particles, n * l->stride, hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->staging.cap != before) ctx->stagedBytes = 0;  // (a grown buffer starts undefined)
+  // Only the fields are written below.  The struct's padding bytes are no part of the reference's contract (its
+  // write-back copies whole structs whose padding is unspecified, ompsph.hpp:479-481): they keep the bytes of the
+  // last uploaded image at that slot — all zero / all equal in practice — instead of costing a second full
+  // host-to-device copy per frame as in round 1; slots never uploaded are zeroed.
+  if (ctx->stagedBytes < n * l->stride) {
+    HIPCHK(ctx, hipMemsetAsync(ctx->staging.as<uint8_t>() + ctx->stagedBytes, 0, n * l->stride - ctx->stagedBytes, ctx->stream));
+    ctx->stagedBytes = n * l->stride;
+  }
+  pin_user_buffer(ctx, particles, n * l->stride);
   AosLayout L{l->stride, l->off_id, l->off_type, l->off_mass, l->off_pos, l->off_vel, l->off_colour};
   if (ctx->fp64)
     hipLaunchKernelGGL((k_pack_aos<double>), grid_for(n), dim3(BLOCK), 0, ctx->stream, uint32_t(n),
@@ -991,7 +1059,8 @@ int pbf_reset_stage_times(pbf_ctx *ctx) {
 namespace {
 
 template <typename N, int MODE>
-int run_select(pbf_ctx *ctx, const pbf_slab_cut *cut, void *sendL, void *sendR, uint32_t cap, uint32_t totals[3]) {
+int run_select(pbf_ctx *ctx, const pbf_slab_cut *cut, void *sendL, void *sendR, uint32_t cap, uint32_t totals[3],
+               bool readback = true) {
   const uint32_t n = uint32_t(ctx->n);
   const uint32_t nb = (n + SEL_TILE - 1) / SEL_TILE;
   if (int rc = ensure(ctx, ctx->selCounts, size_t(3) * std::max(nb, 1u) * 4)) return rc;
@@ -1012,6 +1081,7 @@ int run_select(pbf_ctx *ctx, const pbf_slab_cut *cut, void *sendL, void *sendR, 
                      arrays<N>(ctx, b, b), nb, counts, sendL, sendR, cap, ctx->ghostSrcL.as<uint32_t>(),
                      ctx->ghostSrcR.as<uint32_t>());
   LAUNCH_CHECK(ctx);
+  if (!readback) return PBF_OK;  // (pbf_slab_step reads selTotals back together with the received headers)
   HIPCHK(ctx, hipMemcpyAsync(totals, tot, 12, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the caller needs the counts to size its sends
   return PBF_OK;
@@ -1087,20 +1157,25 @@ template <typename N> int slab_pack(pbf_ctx *ctx, void *sL, void *sR) {
 
 template <typename N> int slab_unpack(pbf_ctx *ctx, const void *rL, const void *rR) {
   const uint32_t m = ctx->gotL + ctx->gotR;
+  StepConsts<N> c;
+  if (!ctx->haveParams) return fail(ctx, PBF_ERR_STATE, "pbf_slab_unpack before any stage");
+  if (int rc = make_consts<N>(ctx, &ctx->lastParams, c)) return rc;
   if (m)
-    hipLaunchKernelGGL((k_unpack_field<N>), grid_for(m), dim3(BLOCK), 0, ctx->stream, ctx->nOwned, ctx->gotL, ctx->gotR,
+    hipLaunchKernelGGL((k_unpack_field<N>), grid_for(m), dim3(BLOCK), 0, ctx->stream, c, ctx->nOwned, ctx->gotL, ctx->gotR,
                        static_cast<const vec4<N> *>(rL), static_cast<const vec4<N> *>(rR),
-                       ctx->slotOf.as<const uint32_t>(), ctx->pstar[ctx->pcur].as<vec4<N>>());
+                       ctx->slotOf.as<const uint32_t>(), ctx->pstar[ctx->pcur].as<vec4<N>>(), ctx->qpos.as<uint2>());
   LAUNCH_CHECK(ctx);
   return PBF_OK;
 }
 
-template <typename N> int slab_finish(pbf_ctx *ctx) {
+template <typename N> int slab_finish(pbf_ctx *ctx, bool knownOwned = false) {
   // drop the copies: the MIGRATE select with no neighbours keeps exactly the non-ghost particles
   pbf_slab_cut none{0, 0xFFFFFFFFu, 0, 0};
   uint32_t t[3];
   const bool wasSorted = ctx->sorted;
-  if (int rc = run_select<N, SEL_MIGRATE>(ctx, &none, nullptr, nullptr, 0, t)) return rc;
+  // (pbf_slab_step knows the count — every non-copy is owned — and skips the synchronising read-back)
+  if (int rc = run_select<N, SEL_MIGRATE>(ctx, &none, nullptr, nullptr, 0, t, !knownOwned)) return rc;
+  if (knownOwned) t[0] = ctx->n ? ctx->nOwned : 0;
   if (ctx->n) {
     ctx->cur = 1 - ctx->cur;
     ctx->pcur = ctx->cur;
@@ -1193,6 +1268,237 @@ int pbf_slab_finish(pbf_ctx *ctx) {
   return DISPATCH(ctx, slab_finish, ctx);
 }
 size_t pbf_owned_count(const pbf_ctx *ctx) { return ctx ? (ctx->slabActive ? ctx->nOwned : ctx->n) : 0; }
+
+int pbf_slab_column_histogram(pbf_ctx *ctx, uint32_t out[1024]) {
+  if (int rc = slab_check(ctx)) return rc;
+  if (!out) return fail(ctx, PBF_ERR_INVALID, "NULL argument");
+  if (int rc = ensure(ctx, ctx->selTotals, 16)) return rc;
+  if (int rc = ensure(ctx, ctx->colHist, 1024 * 4)) return rc;
+  HIPCHK(ctx, hipMemsetAsync(ctx->colHist.p, 0, 1024 * 4, ctx->stream));
+  if (ctx->n) {
+    const uint32_t blocks = uint32_t(std::min<size_t>((ctx->n + BLOCK - 1) / BLOCK, size_t(ctx->numCUs) * 4));
+    hipLaunchKernelGGL(k_column_histogram, dim3(blocks), dim3(BLOCK), 0, ctx->stream, uint32_t(ctx->n),
+                       ctx->slabConfigured ? ctx->xoff : 0u, ctx->key[ctx->cur].as<const uint32_t>(),
+                       ctx->type[ctx->cur].as<const uint8_t>(), ctx->colHist.as<uint32_t>());
+    LAUNCH_CHECK(ctx);
+  }
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->colHist.p, 1024 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PBF_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// Communicator + the whole slab step inside the library (include/pbf_hip.h "communicator")
+// ================================================================================================
+namespace {
+
+thread_local std::string g_comm_error;
+
+pbf_slab_cut cut_of(const pbf_ctx *ctx) {
+  const int r = ctx->comm->rank, n = ctx->comm->nranks;
+  return pbf_slab_cut{ctx->cuts[r], ctx->cuts[r + 1], r > 0 ? 1 : 0, r + 1 < n ? 1 : 0};
+}
+
+int apply_cuts(pbf_ctx *ctx) {
+  const int r = ctx->comm->rank, n = ctx->comm->nranks;
+  if (n == 1) return pbf_slab_configure(ctx, nullptr, 0, 0);
+  const pbf_slab_cut c = cut_of(ctx);
+  return pbf_slab_configure(ctx, &c, r > 0 ? ctx->cuts[r - 1] : 0, r + 1 < n ? ctx->cuts[r + 1] : 0);
+}
+
+int exchange(pbf_ctx *ctx, size_t nSL, size_t nSR, size_t nRL, size_t nRR) {
+  const int rc = comm_exchange(ctx->comm, ctx->stream, ctx->wireSend[0].p, nSL, ctx->wireSend[1].p, nSR, ctx->wireRecv[0].p,
+                               nRL, ctx->wireRecv[1].p, nRR);
+  if (rc) ctx->err = "slab exchange: " + ctx->comm->err;
+  return rc;
+}
+
+// One assembly round: select + pack (MODE), counts into the message headers, ONE exchange of capacity-sized
+// messages, then one small read-back {own totals[3], header from the left, header from the right}.
+template <typename N, int MODE>
+int assembly_round(pbf_ctx *ctx, uint32_t cap, size_t recBytes, int idxL, int idxR, uint32_t own[3], uint32_t got[2]) {
+  const pbf_slab_cut cut = cut_of(ctx);
+  uint8_t *sL = ctx->wireSend[0].as<uint8_t>(), *sR = ctx->wireSend[1].as<uint8_t>();
+  uint8_t *rL = ctx->wireRecv[0].as<uint8_t>(), *rR = ctx->wireRecv[1].as<uint8_t>();
+  uint32_t t[3];
+  if (int rc = ensure(ctx, ctx->selTotals, 16)) return rc;
+  if (ctx->n == 0) HIPCHK(ctx, hipMemsetAsync(ctx->selTotals.p, 0, 16, ctx->stream));
+  if (int rc = run_select<N, MODE>(ctx, &cut, sL + WIRE_HDR, sR + WIRE_HDR, cap, t, false)) return rc;
+  hipLaunchKernelGGL(k_wire_headers, dim3(1), dim3(64), 0, ctx->stream, ctx->selTotals.as<const uint32_t>(), idxL, idxR,
+                     reinterpret_cast<uint32_t *>(sL), reinterpret_cast<uint32_t *>(sR));
+  LAUNCH_CHECK(ctx);
+  const size_t bytes = WIRE_HDR + size_t(cap) * recBytes;
+  // a rank without that neighbour neither sends nor receives on that side: its header reads 0
+  HIPCHK(ctx, hipMemsetAsync(rL, 0, WIRE_HDR, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(rR, 0, WIRE_HDR, ctx->stream));
+  if (int rc = exchange(ctx, bytes, bytes, bytes, bytes)) return rc;
+  uint32_t *h = ctx->hostCounts;
+  HIPCHK(ctx, hipMemcpyAsync(h, ctx->selTotals.p, 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(h + 4, rL, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(h + 5, rR, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the one read-back of this round: counts size the launches below
+  own[0] = h[0], own[1] = h[1], own[2] = h[2];
+  got[0] = h[4], got[1] = h[5];
+  if (own[idxL] > cap || own[idxR] > cap || got[0] > cap || got[1] > cap)
+    return fail(ctx, PBF_ERR_COMM, "slab wire capacity exceeded (" + std::to_string(std::max(std::max(own[idxL], own[idxR]), std::max(got[0], got[1]))) +
+                                       " records > " + std::to_string(cap) + "): attach with larger capacities");
+  return PBF_OK;
+}
+
+template <typename N> int slab_step_impl(pbf_ctx *ctx, const pbf_params *p) {
+  if (int rc = stage_predict<N>(ctx, p)) return rc;
+  const uint8_t *rL = ctx->wireRecv[0].as<const uint8_t>() + WIRE_HDR, *rR = ctx->wireRecv[1].as<const uint8_t>() + WIRE_HDR;
+  uint32_t own[3], got[2];
+  // ---- round 1: particles whose cell column left the slab move to the neighbour --------------------------
+  if (int rc = drop_histogram(ctx)) return rc;  // predict's histogram describes the pre-migration set
+  if (int rc = assembly_round<N, SEL_MIGRATE>(ctx, ctx->capMig, sizeof(MigrantRec<N>), 1, 2, own, got)) return rc;
+  if (ctx->n) ctx->cur = 1 - ctx->cur, ctx->pcur = ctx->cur;  // the keeps were compacted into the other array set
+  ctx->n = own[0], ctx->nOwned = own[0], ctx->sorted = false;
+  if (int rc = slab_add_migrants<N>(ctx, rL, got[0], rR, got[1])) return rc;
+  // ---- round 2: copies of the boundary columns ------------------------------------------------------------
+  if (int rc = assembly_round<N, SEL_GHOST>(ctx, ctx->capGhost, sizeof(GhostRec<N>), 0, 1, own, got)) return rc;
+  ctx->sentL = own[0], ctx->sentR = own[1];
+  if (int rc = slab_add_ghosts<N>(ctx, rL, got[0], rR, got[1])) return rc;
+  if (int rc = stage_sort<N>(ctx, p)) return rc;
+  if (int rc = stage_diffuse<N>(ctx, p)) return rc;
+  // ---- K x { lambda, delta-p }, each followed by the owners refreshing their copies' {pStar, lambda} ------
+  const size_t fb = sizeof(vec4<N>);
+  auto refresh = [&]() -> int {
+    if (int rc = slab_pack<N>(ctx, ctx->wireSend[0].p, ctx->wireSend[1].p)) return rc;
+    if (int rc = exchange(ctx, ctx->sentL * fb, ctx->sentR * fb, ctx->gotL * fb, ctx->gotR * fb)) return rc;
+    return slab_unpack<N>(ctx, ctx->wireRecv[0].p, ctx->wireRecv[1].p);
+  };
+  for (uint64_t it = 0; it < p->iteration; ++it) {
+    if (int rc = stage_lambda<N>(ctx, p)) return rc;
+    if (int rc = refresh()) return rc;
+    if (int rc = stage_delta<N>(ctx, p)) return rc;
+    if (int rc = refresh()) return rc;
+  }
+  if (int rc = stage_finalise<N>(ctx, p)) return rc;
+  return slab_finish<N>(ctx, /*knownOwned=*/true);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pbf_comm_last_error(const pbf_comm *comm) { return comm ? comm->err.c_str() : g_comm_error.c_str(); }
+uint64_t pbf_comm_rounds(const pbf_comm *comm) { return comm ? comm->rounds : 0; }
+
+int pbf_comm_unique_id(void *id128) {
+  if (!id128) return PBF_ERR_INVALID;
+  pbf_comm tmp;
+  if (!comm_load_rccl(&tmp)) {
+    g_comm_error = tmp.err;
+    return PBF_ERR_COMM;
+  }
+  ncclUniqueId id;
+  const ncclResult_t r = tmp.fGetUniqueId(&id);
+  if (r != ncclSuccess) {
+    g_comm_error = std::string("ncclGetUniqueId: ") + tmp.fErrorString(r);
+    return PBF_ERR_COMM;
+  }
+  static_assert(sizeof(id) == PBF_COMM_ID_BYTES, "ncclUniqueId size");
+  std::memcpy(id128, &id, sizeof(id));
+  return PBF_OK;
+}
+
+int pbf_comm_create_rccl(const void *id128, int nranks, int rank, int device, pbf_comm **out) {
+  if (!id128 || !out || nranks < 1 || rank < 0 || rank >= nranks) {
+    g_comm_error = "pbf_comm_create_rccl: bad argument";
+    return PBF_ERR_INVALID;
+  }
+  *out = nullptr;
+  auto *c = new pbf_comm();
+  c->nranks = nranks, c->rank = rank, c->device = device;
+  if (!comm_load_rccl(c)) {
+    g_comm_error = c->err;
+    delete c;
+    return PBF_ERR_COMM;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    g_comm_error = "hipSetDevice failed";
+    delete c;
+    return PBF_ERR_HIP;
+  }
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  const ncclResult_t r = c->fCommInitRank(&c->comm, nranks, id, rank);
+  if (r != ncclSuccess) {
+    g_comm_error = std::string("ncclCommInitRank: ") + c->fErrorString(r);
+    delete c;
+    return PBF_ERR_COMM;
+  }
+  *out = c;
+  return PBF_OK;
+}
+
+int pbf_comm_create_host_callback(pbf_exchange_fn fn, void *user, int nranks, int rank, pbf_comm **out) {
+  if (!fn || !out || nranks < 1 || rank < 0 || rank >= nranks) {
+    g_comm_error = "pbf_comm_create_host_callback: bad argument";
+    return PBF_ERR_INVALID;
+  }
+  auto *c = new pbf_comm();
+  c->nranks = nranks, c->rank = rank, c->fn = fn, c->user = user;
+  *out = c;
+  return PBF_OK;
+}
+
+void pbf_comm_destroy(pbf_comm *c) {
+  if (!c) return;
+  if (c->comm && c->fCommDestroy) (void)c->fCommDestroy(c->comm);
+  for (void *h : c->host)
+    if (h) (void)hipHostFree(h);
+  delete c;  // (the dlopen handle stays: other communicators / the hosting process may use librccl)
+}
+
+int pbf_comm_allreduce_u32(pbf_comm *c, void *device_u32, size_t count, void *stream) {
+  if (!c || !device_u32) return PBF_ERR_INVALID;
+  if (!c->comm) {
+    c->err = "pbf_comm_allreduce_u32 needs an RCCL communicator";
+    return PBF_ERR_COMM;
+  }
+  const ncclResult_t r = c->fAllReduce(device_u32, device_u32, count, ncclUint32, ncclSum, c->comm, static_cast<hipStream_t>(stream));
+  return r == ncclSuccess ? PBF_OK : comm_fail(c, "ncclAllReduce", r);
+}
+
+int pbf_slab_set_cuts(pbf_ctx *ctx, const uint32_t *cuts) {
+  if (int rc = slab_check(ctx)) return rc;
+  if (!ctx->comm || !cuts) return fail(ctx, PBF_ERR_STATE, "pbf_slab_set_cuts needs pbf_slab_attach first");
+  const int n = ctx->comm->nranks;
+  for (int g = 0; g < n; ++g)
+    if (cuts[g + 1] <= cuts[g]) return fail(ctx, PBF_ERR_INVALID, "cuts must be strictly increasing");
+  ctx->cuts.assign(cuts, cuts + n + 1);
+  return apply_cuts(ctx);
+}
+
+int pbf_slab_attach(pbf_ctx *ctx, pbf_comm *comm, const uint32_t *cuts, uint32_t cap_migrants, uint32_t cap_ghosts) {
+  if (int rc = slab_check(ctx)) return rc;
+  if (!comm || !cuts || !cap_migrants || !cap_ghosts) return fail(ctx, PBF_ERR_INVALID, "NULL / zero argument");
+  ctx->comm = comm;
+  ctx->capMig = cap_migrants, ctx->capGhost = cap_ghosts;
+  const size_t mig = ctx->fp64 ? sizeof(MigrantRec<double>) : sizeof(MigrantRec<float>);
+  const size_t gho = ctx->fp64 ? sizeof(GhostRec<double>) : sizeof(GhostRec<float>);
+  const size_t bytes = WIRE_HDR + std::max(size_t(cap_migrants) * mig, size_t(cap_ghosts) * gho);
+  for (int k = 0; k < 2; ++k) {
+    if (int rc = ensure(ctx, ctx->wireSend[k], bytes)) return rc;
+    if (int rc = ensure(ctx, ctx->wireRecv[k], bytes)) return rc;
+  }
+  if (!ctx->hostCounts) HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->hostCounts), 64, hipHostMallocDefault));
+  return pbf_slab_set_cuts(ctx, cuts);
+}
+
+int pbf_slab_step(pbf_ctx *ctx, const pbf_params *p) { return pbf_slab_steps(ctx, p, 1); }
+int pbf_slab_steps(pbf_ctx *ctx, const pbf_params *p, uint32_t count) {
+  if (int rc = check(ctx, p, false)) return rc;
+  if (!ctx->comm) return fail(ctx, PBF_ERR_STATE, "pbf_slab_step needs pbf_slab_attach first");
+  if (p->vorticity || p->xsph) return fail(ctx, PBF_ERR_INVALID, "vorticity / xsph are not available in slab mode yet");
+  for (uint32_t i = 0; i < count; ++i)
+    if (int rc = DISPATCH(ctx, slab_step_impl, ctx, p)) return rc;
+  return PBF_OK;
+}
 
 }  // extern "C"
 

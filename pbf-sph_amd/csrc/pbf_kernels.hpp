@@ -154,6 +154,28 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Quantised positions (the list build's 8-byte candidates, see k_build_lists_q): written by every producer of a
+// sorted pStar — the sort's move, delta-p's epilogue, the slab refresh — so no pass of its own is needed.
+// ------------------------------------------------------------------------------------------------
+constexpr int QPOS_BITS = 11;                       // sub-cell resolution h / 2048
+// Threshold: a pair the exact test accepts has |d| <= 2048 (1 + 1e-5) units; per axis the quantised difference
+// is off by < 1 (two floors) + 1.5 (fp32 rounding of (p - min) * k for |coordinate| < 2^22 units: 3 roundings
+// of <= 0.25 each, two particles), so |dq| < 2048.03 + 2.5 sqrt(3) = 2052.4 < T.
+constexpr uint32_t QPOS_T = (1u << QPOS_BITS) + 5;
+typedef short qpair __attribute__((ext_vector_type(2)));
+
+template <typename N> __device__ inline uint2 quantise_position(const StepConsts<N> &c, const vec4<N> &p, bool *usable) {
+  const N k = N(1u << QPOS_BITS) / c.h;
+  const N fx = floor((p.x - c.minExtent[0]) * k), fy = floor((p.y - c.minExtent[1]) * k),
+          fz = floor((p.z - c.minExtent[2]) * k);
+  const N lim = N(1 << 22);
+  *usable = fabs(fx) < lim && fabs(fy) < lim && fabs(fz) < lim;  // (false for NaN too)
+  const uint32_t x = uint32_t(int32_t(fx)), y = uint32_t(int32_t(fy)), z = uint32_t(int32_t(fz));
+  return make_uint2((x & 0xFFFFu) | (y << 16), z & 0xFFFFu);
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // Counting-sort scatter, made deterministic                      (reference: ompsph.hpp:157-159)
 //   pass A: slot inside the cell from an atomic (arbitrary order), records the source index;
 //           atomicSub returns the histogram to zero for the next step (no memset);
@@ -161,15 +183,68 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t *__restrict
 //           source index, i.e. a STABLE sort by key — run-to-run reproducible — then the whole
 //           record moves to its sorted slot (writes stay inside one cell's short range).
 // ------------------------------------------------------------------------------------------------
+//   pile-ups: pass B's rank is a count over the cell's m members — O(m) per particle.  A cell with more than
+//           BIG_CELL members (fluid piled into one cell, or the overflow bucket of particles outside the grid) is
+//           listed by pass A and its segment of permTmp is SORTED first (k_sort_big_cells, O(m log^2 m) per cell);
+//           pass B then reads the rank off the position.  Same permutation either way.
+constexpr uint32_t BIG_CELL = 2048;
+
 __global__ __launch_bounds__(BLOCK) void k_scatter_slots(uint32_t n, uint32_t tableN, const uint32_t *__restrict__ key,
                                                          const uint32_t *__restrict__ table,
                                                          uint32_t *__restrict__ count,
-                                                         uint32_t *__restrict__ permTmp) {
+                                                         uint32_t *__restrict__ permTmp,
+                                                         uint32_t *__restrict__ bigCells,
+                                                         uint32_t *__restrict__ nBig) {
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint32_t b = min(key[i], tableN);
-  const uint32_t r = atomicSub(&count[b], 1u) - 1u;
+  const uint32_t r = atomicSub(&count[b], 1u) - 1u;  // r runs m - 1 .. 0 over the cell's m members
   permTmp[table[b] + r] = i;
+  if (r == BIG_CELL) bigCells[atomicAdd(nBig, 1u)] = b;  // exactly one member of a cell with m > BIG_CELL sees this
+}
+
+// In-place bitonic sort (all compare-exchanges ascending: the "mirror" form, so the virtual +inf padding beyond the
+// segment never moves) of the permTmp segment of every listed cell; one workgroup per cell, grid-strided.  Ordinary
+// cells order by source index; the overflow bucket (keys differ) by (key, source index).
+__global__ __launch_bounds__(BLOCK) void k_sort_big_cells(const uint32_t *__restrict__ table, uint32_t tableN,
+                                                          const uint32_t *__restrict__ bigCells,
+                                                          const uint32_t *__restrict__ nBig,
+                                                          uint32_t *__restrict__ permTmp,
+                                                          const uint32_t *__restrict__ key) {
+  const uint32_t cells = *nBig;
+  for (uint32_t c = blockIdx.x; c < cells; c += gridDim.x) {
+    const uint32_t b = bigCells[c];
+    const uint32_t lo = table[b], m = table[b + 1] - lo;
+    uint32_t *a = permTmp + lo;
+    const bool byKey = b == tableN;
+    auto exchange = [&](uint32_t i, uint32_t l) {  // i < l < m
+      const uint32_t x = a[i], y = a[l];
+      bool swap;
+      if (byKey) {
+        const uint32_t kx = key[x], ky = key[y];
+        swap = ky < kx || (ky == kx && y < x);
+      } else {
+        swap = y < x;
+      }
+      if (swap) a[i] = y, a[l] = x;
+    };
+    uint32_t P = 1;
+    while (P < m) P <<= 1;
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+      for (uint32_t i = threadIdx.x; i < m; i += BLOCK) {
+        const uint32_t l = i ^ (k - 1u);
+        if (l > i && l < m) exchange(i, l);
+      }
+      __syncthreads();
+      for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+        for (uint32_t i = threadIdx.x; i < m; i += BLOCK) {
+          const uint32_t l = i ^ j;
+          if (l > i && l < m) exchange(i, l);
+        }
+        __syncthreads();
+      }
+    }
+  }
 }
 
 template <typename N> struct ParticleArrays {
@@ -180,10 +255,11 @@ template <typename N> struct ParticleArrays {
 };
 
 template <typename N>
-__global__ __launch_bounds__(BLOCK) void k_rank_move(uint32_t n, uint32_t tableN,
+__global__ __launch_bounds__(BLOCK) void k_rank_move(StepConsts<N> c, uint32_t n, uint32_t tableN,
                                                      const uint32_t *__restrict__ permTmp,
                                                      const uint32_t *__restrict__ table, ParticleArrays<N> src,
-                                                     ParticleArrays<N> dst, uint32_t *__restrict__ slotOf) {
+                                                     ParticleArrays<N> dst, uint32_t *__restrict__ slotOf,
+                                                     uint2 *__restrict__ qpos) {
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint32_t s = permTmp[i];
@@ -191,7 +267,9 @@ __global__ __launch_bounds__(BLOCK) void k_rank_move(uint32_t n, uint32_t tableN
   const uint32_t b = min(k, tableN);
   const uint32_t lo = table[b], hi = table[b + 1];
   uint32_t rank = 0;
-  if (b < tableN) {
+  if (hi - lo > BIG_CELL) {
+    rank = i - lo;  // k_sort_big_cells has sorted this segment
+  } else if (b < tableN) {
     for (uint32_t j = lo; j < hi; ++j) rank += (permTmp[j] < s) ? 1u : 0u;
   } else {
     // overflow bucket (particles in no cell): keys differ, order by (key, source index) so that the
@@ -206,7 +284,10 @@ __global__ __launch_bounds__(BLOCK) void k_rank_move(uint32_t n, uint32_t tableN
   dst.pos4[d] = src.pos4[s];
   dst.vel4[d] = src.vel4[s];
   dst.col4[d] = src.col4[s];
-  dst.pstar[d] = src.pstar[s];
+  const vec4<N> ps = src.pstar[s];
+  dst.pstar[d] = ps;
+  bool usable;
+  qpos[d] = quantise_position<N>(c, ps, &usable);  // what the first list build of the step tests candidates on
   dst.id[d] = src.id[s];
   dst.type[d] = src.type[s];
   dst.key[d] = k;
@@ -438,6 +519,7 @@ template <typename N, bool FAST> struct DeltaOp {
     const vec4<N> *pstarIn;
     vec4<N> *pstarOut;
     const uint8_t *type;
+    uint2 *qpos;  // may be NULL: the quantised copy of pstarOut for the next iteration's list build
   };
   static constexpr bool kNeedsCandidateType = false;
   static constexpr bool kFilter = true;
@@ -487,7 +569,12 @@ template <typename N, bool FAST> struct DeltaOp {
     x = min(c.maxB[0], max(c.minB[0], x));
     y = min(c.maxB[1], max(c.minB[1], y));
     z = min(c.maxB[2], max(c.minB[2], z));
-    a.pstarOut[i] = make_vec4<N>(x / c.scale, y / c.scale, z / c.scale, pa.w);
+    const vec4<N> out = make_vec4<N>(x / c.scale, y / c.scale, z / c.scale, pa.w);
+    a.pstarOut[i] = out;
+    if (a.qpos) {
+      bool usable;
+      a.qpos[i] = quantise_position<N>(c, out, &usable);
+    }
   }
 };
 
@@ -1201,23 +1288,6 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists(StepConsts<N> c, const ve
 // ever a SUPERSET of the particles within h (rounding is covered by the threshold, wrap-around and
 // overflow can only add far candidates); the list-driven ops apply the exact tests, so the physics
 // stays bit-identical.  A walker whose own coordinates are unusable (outside +-2^22 units) takes all.
-constexpr int QPOS_BITS = 11;                       // sub-cell resolution h / 2048
-// Threshold: a pair the exact test accepts has |d| <= 2048 (1 + 1e-5) units; per axis the quantised difference
-// is off by < 1 (two floors) + 1.5 (fp32 rounding of (p - min) * k for |coordinate| < 2^22 units: 3 roundings
-// of <= 0.25 each, two particles), so |dq| < 2048.03 + 2.5 sqrt(3) = 2052.4 < T.
-constexpr uint32_t QPOS_T = (1u << QPOS_BITS) + 5;
-typedef short qpair __attribute__((ext_vector_type(2)));
-
-template <typename N> __device__ inline uint2 quantise_position(const StepConsts<N> &c, const vec4<N> &p, bool *usable) {
-  const N k = N(1u << QPOS_BITS) / c.h;
-  const N fx = floor((p.x - c.minExtent[0]) * k), fy = floor((p.y - c.minExtent[1]) * k),
-          fz = floor((p.z - c.minExtent[2]) * k);
-  const N lim = N(1 << 22);
-  *usable = fabs(fx) < lim && fabs(fy) < lim && fabs(fz) < lim;  // (false for NaN too)
-  const uint32_t x = uint32_t(int32_t(fx)), y = uint32_t(int32_t(fy)), z = uint32_t(int32_t(fz));
-  return make_uint2((x & 0xFFFFu) | (y << 16), z & 0xFFFFu);
-}
-
 template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_quantise(StepConsts<N> c, const vec4<N> *__restrict__ pstar,
                                                     uint2 *__restrict__ qpos) {

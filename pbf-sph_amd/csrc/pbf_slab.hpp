@@ -156,6 +156,17 @@ __global__ __launch_bounds__(BLOCK) void k_sel_emit(uint32_t n, SlabCut s, Parti
   }
 }
 
+// Assembly rounds of pbf_slab_step: the wire message is {header (WIRE_HDR bytes: record count) | capacity-sized record
+// array}; the counts never travel on their own.
+constexpr size_t WIRE_HDR = 32;  // keeps the records 32-byte aligned (double4)
+__global__ void k_wire_headers(const uint32_t *__restrict__ totals, int idxL, int idxR, uint32_t *__restrict__ hdrL,
+                               uint32_t *__restrict__ hdrR) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    hdrL[0] = totals[idxL];
+    hdrR[0] = totals[idxR];
+  }
+}
+
 // A record keyed in the sender's rank-local x frame is re-keyed into ours: x' = x + shift (cells).
 __device__ inline uint32_t shift_key_x(uint32_t key, int32_t shift) {
   const uint32_t x = (compact10(key) + uint32_t(shift)) & 1023u;
@@ -195,6 +206,20 @@ __global__ __launch_bounds__(BLOCK) void k_count_keys(uint32_t n, uint32_t table
   if (i < n) atomicAdd(&count[min(key[i], tableN)], 1u);
 }
 
+// owned particles per GLOBAL grid column (1024 bins, LDS-privatised): the load-balance input of the slab driver
+__global__ __launch_bounds__(BLOCK) void k_column_histogram(uint32_t n, uint32_t xoff, const uint32_t *__restrict__ key,
+                                                            const uint8_t *__restrict__ type,
+                                                            uint32_t *__restrict__ hist) {
+  __shared__ uint32_t h[1024];
+  for (uint32_t j = threadIdx.x; j < 1024; j += BLOCK) h[j] = 0;
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+    if (!(type[i] & TYPE_GHOST)) atomicAdd(&h[(compact10(key[i]) + xoff) & 1023u], 1u);
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < 1024; j += BLOCK)
+    if (h[j]) atomicAdd(&hist[j], h[j]);
+}
+
 // owners -> copies: {pStar, lambda} of the particles listed in srcL / srcR, read at their sorted slot
 template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_pack_field(uint32_t nL, uint32_t nR, const uint32_t *__restrict__ srcL,
@@ -209,14 +234,18 @@ __global__ __launch_bounds__(BLOCK) void k_pack_field(uint32_t nL, uint32_t nR, 
 
 // copies <- owners: the copies sit at pre-sort indices ghostAt + j in arrival order (left, then right)
 template <typename N>
-__global__ __launch_bounds__(BLOCK) void k_unpack_field(uint32_t ghostAt, uint32_t nL, uint32_t nR,
+__global__ __launch_bounds__(BLOCK) void k_unpack_field(StepConsts<N> c, uint32_t ghostAt, uint32_t nL, uint32_t nR,
                                                         const vec4<N> *__restrict__ inL,
                                                         const vec4<N> *__restrict__ inR,
                                                         const uint32_t *__restrict__ slotOf,
-                                                        vec4<N> *__restrict__ pstar) {
+                                                        vec4<N> *__restrict__ pstar, uint2 *__restrict__ qpos) {
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
   if (j >= nL + nR) return;
-  pstar[slotOf[ghostAt + j]] = j < nL ? inL[j] : inR[j - nL];
+  const vec4<N> v = j < nL ? inL[j] : inR[j - nL];
+  const uint32_t d = slotOf[ghostAt + j];
+  pstar[d] = v;
+  bool usable;
+  qpos[d] = quantise_position<N>(c, v, &usable);  // keeps the list build's quantised copy in step with pStar
 }
 
 }  // namespace pbf

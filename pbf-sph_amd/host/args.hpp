@@ -30,6 +30,8 @@ struct Args {
   bool surface = true;                    // --no-surface: skip marching cubes (stock: on, benchmark.cpp:29)
   bool fastMath = false;                  // --fast-math
   bool json = false;                      // --json: one machine-readable line after the summary
+  bool allDevices = false;                // --all-devices: EVERY device matching -d becomes one x-slab (RCCL halo)
+  size_t slabs = 0;                       // --slabs K: K slabs on the first matching device (in-process exchange: tests)
 
   Args(size_t defaultIterations, std::string defaultOutput)
       : iterations(defaultIterations), output(std::move(defaultOutput)) {}
@@ -60,7 +62,10 @@ struct Args {
           "      --resident                        Time the device-resident loop (no per-frame host round trip)\n"
           "      --no-surface                      Skip the marching-cubes surface (the stock driver runs with it on)\n"
           "      --fast-math                       v_rsq / fma pair kernels (the reference builds with -Ofast)\n"
-          "      --json                            Print one JSON line with the results\n";
+          "      --json                            Print one JSON line with the results\n"
+          "      --all-devices                     Use EVERY device matching -d: one x-slab per GPU, ghost-layer\n"
+          "                                        exchange over RCCL (implies --resident --no-surface)\n"
+          "      --slabs=[K]                       K slabs on the first matching device (in-process exchange; tests)\n";
   }
 
   // returns false if the program should exit (help / parse error), like the reference's parse()
@@ -96,6 +101,8 @@ struct Args {
         else if (a == "--no-surface") surface = false;
         else if (a == "--fast-math") fastMath = true;
         else if (a == "--json") json = true;
+        else if (a == "--all-devices") allDevices = true;
+        else if (value(i, a, "", "--slabs", v)) slabs = std::stoull(v);
         else if (value(i, a, "-i", "--impl", v)) impl = v;
         else if (value(i, a, "-d", "--devices", v)) devices.push_back(v);
         else if (value(i, a, "-n", "--iter", v)) iterations = std::stoull(v);

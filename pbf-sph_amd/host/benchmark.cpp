@@ -48,12 +48,14 @@ std::vector<std::pair<int, std::string>> listDevices() {
   return out;
 }
 
-// first device matching any needle: an index or a substring of the name (src/utils.hpp:87-105,128-159)
-int findDevice(const sph::driver::Args &args) {
+// devices matching any needle: an index or a substring of the name (src/utils.hpp:87-105,128-159).  The reference
+// takes the FIRST match; --all-devices takes every match (one x-slab each), --slabs K repeats the first K times.
+std::vector<int> findDevices(const sph::driver::Args &args) {
   const auto devices = listDevices();
+  std::vector<int> out;
   if (args.list) {
     for (const auto &[i, name] : devices) std::cout << "[" << i << "] " << name << std::endl;
-    return -1;
+    return out;
   }
   for (const auto &[i, name] : devices)
     for (const auto &needle : args.devices) {
@@ -65,16 +67,17 @@ int findDevice(const sph::driver::Args &args) {
       } catch (...) {
         match = name.find(needle) != std::string::npos;
       }
-      if (match) {
+      if (match && (out.empty() || (args.allDevices && out.back() != i))) {
         std::cout << "Using device: " << name << std::endl;
-        return i;
+        out.push_back(i);
       }
     }
-  std::cerr << "No device matches the --devices list" << std::endl;
-  return -1;
+  if (out.empty()) std::cerr << "No device matches the --devices list" << std::endl;
+  if (!out.empty() && args.slabs > 1) out.assign(args.slabs, out.front());
+  return out;
 }
 
-template <typename N> int run(const sph::driver::Args &args, int device) {
+template <typename N> int run(sph::driver::Args args, const std::vector<int> &devices) {
   using T = size_t;
   using Particle = sph::Particle<T, N, sph::vec>;
   const auto output = args.renderedOutputName();
@@ -94,13 +97,19 @@ template <typename N> int run(const sph::driver::Args &args, int device) {
   if (args.surface) param.surface = mc;
 
   uint32_t flags = (args.fastMath ? PBF_FLAG_FAST_MATH : 0u) | (args.verbose ? PBF_FLAG_STAGE_TIMING : 0u);
-  sph::hip_impl::Solver<T, N> solver(N(0.1), device, flags);
+  const bool slabbed = devices.size() > 1;
+  if (slabbed) {  // x-slabs: device-resident stepping; the surface is a single-device feature
+    if (!args.resident || args.surface) std::cout << "Slab mode (" << devices.size() << " slabs): --resident --no-surface implied" << std::endl;
+    args.resident = true, args.surface = false;
+    param.surface.reset();
+  }
+  sph::hip_impl::Solver<T, N> solver(N(0.1), devices, flags);
   sph::Result<T, N, sph::vec> result;
   auto frameParam = [&](size_t frame) { return moving ? sph::applyMotionSinXCosZ(param, frame) : param; };
 
   std::vector<double> frameTime;
   hrc::time_point start, end;
-  if (args.resident) solver.upload(particles);
+  if (args.resident) solver.upload(particles, &param);
   auto one = [&](size_t frame) {
     if (args.resident) {
       solver.step(frameParam(frame));
@@ -161,7 +170,7 @@ template <typename N> int run(const sph::driver::Args &args, int device) {
   if (args.json)
     std::cout << "{\"impl\":\"hip\",\"scene\":\"" << args.scene << "\",\"particles\":" << particles.size()
               << ",\"solver_iter\":" << args.solverIter << ",\"fp64\":" << (args.fp64 ? "true" : "false")
-              << ",\"resident\":" << (args.resident ? "true" : "false") << ",\"frames\":" << frames
+              << ",\"resident\":" << (args.resident ? "true" : "false") << ",\"slabs\":" << devices.size() << ",\"frames\":" << frames
               << ",\"seconds\":" << seconds << ",\"particle_steps_per_s\":" << psps << ",\"frame_ms_mean\":" << st.mean
               << "}" << std::endl;
   sph::save(result, particles, output);
@@ -179,10 +188,10 @@ int main(int argc, char *argv[]) {
               << "(omp/ocl/sycl live in the reference)" << std::endl;
     return EXIT_FAILURE;
   }
-  const int device = findDevice(args);
-  if (device < 0) return args.list ? EXIT_SUCCESS : EXIT_FAILURE;
+  const std::vector<int> devices = findDevices(args);
+  if (devices.empty()) return args.list ? EXIT_SUCCESS : EXIT_FAILURE;
   try {
-    return args.fp64 ? run<double>(args, device) : run<float>(args, device);
+    return args.fp64 ? run<double>(args, devices) : run<float>(args, devices);
   } catch (const std::exception &e) {
     std::cerr << "benchmark failed: " << e.what() << std::endl;
     return EXIT_FAILURE;

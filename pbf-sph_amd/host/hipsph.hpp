@@ -9,6 +9,14 @@
 //                      src/ocl/oclsph.cpp:427-473);
 //   upload()/step()/download()   the device-resident fast path the benchmark times as well.
 //
+//   Solver(h, {d0, d1, ...})     several GPUs of one node (reference: the -d/--devices list, src/args.cpp:20-24):
+//                      the box is cut into x-slabs with equal particle counts, one ctx + one host thread per
+//                      device, every step runs pbf_slab_step on all of them concurrently with the neighbour
+//                      exchange over RCCL (ncclSend/ncclRecv, xGMI) inside the library; cuts are re-balanced
+//                      every few steps from the all-device column histogram.  Devices listed more than once share
+//                      a GPU and exchange through an in-process transport (RCCL refuses two ranks on one GPU):
+//                      the same code path, used by the tests on a one-GPU box.
+//
 // Host-side scene handling restates the observable behaviour of ompsph.hpp:91-126 (sources emit,
 // drains erase, empty -> "Particles depleted") and :167-186 (queries).  config.surface runs the
 // marching-cubes kernels (pbf_surface) and fills Result::mesh like ompsph.hpp:277-477.
@@ -17,6 +25,11 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -27,6 +40,72 @@
 
 namespace sph::hip_impl {
 
+namespace detail {
+
+// One direction of a link between two slabs that share a GPU: the sender posts its (pinned host) buffer, the receiver
+// copies it out.  Used through pbf_comm_create_host_callback; never on the RCCL path.
+struct Mailbox {
+  std::mutex m;
+  std::condition_variable cv;
+  const void *data = nullptr;
+  size_t bytes = 0;
+  bool full = false;
+  void post(const void *d, size_t n) {
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { return !full; });
+    data = d, bytes = n, full = true;
+    cv.notify_all();
+  }
+  void take(void *dst, size_t n) {
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { return full; });
+    std::memcpy(dst, data, std::min(n, bytes));
+    full = false;
+    cv.notify_all();
+  }
+  void drained() {
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { return !full; });
+  }
+};
+struct InProcessLink {  // rank's view: mailboxes to / from both neighbours
+  Mailbox *toLeft = nullptr, *toRight = nullptr, *fromLeft = nullptr, *fromRight = nullptr;
+  static int exchange(void *user, const void *sL, size_t nSL, const void *sR, size_t nSR, void *rL, size_t nRL, void *rR,
+                      size_t nRR) {
+    auto *k = static_cast<InProcessLink *>(user);
+    if (nSL && k->toLeft) k->toLeft->post(sL, nSL);
+    if (nSR && k->toRight) k->toRight->post(sR, nSR);
+    if (nRL && k->fromLeft) k->fromLeft->take(rL, nRL);
+    if (nRR && k->fromRight) k->fromRight->take(rR, nRR);
+    if (nSL && k->toLeft) k->toLeft->drained();  // our staging buffers are free again once the neighbours copied
+    if (nSR && k->toRight) k->toRight->drained();
+    return 0;
+  }
+};
+
+// slab.py recut(): particle-count quantiles of the column histogram, each cut moved by at most `maxMove` columns
+// (a transferred column always goes to the ADJACENT slab) and slabs kept >= minWidth columns wide.
+inline std::vector<uint32_t> recut(const std::vector<uint32_t> &old, const std::vector<uint64_t> &hist, int maxMove = 2,
+                                   int minWidth = 4) {
+  const int n = int(old.size()) - 1;
+  std::vector<uint64_t> cum(hist.size() + 1, 0);
+  for (size_t c = 0; c < hist.size(); ++c) cum[c + 1] = cum[c] + hist[c];
+  const double total = double(cum.back());
+  std::vector<long> nw(old.begin(), old.end());
+  auto clampMove = [&](int g) { nw[g] = std::min<long>(std::max<long>(nw[g], long(old[g]) - maxMove), long(old[g]) + maxMove); };
+  for (int g = 1; g < n; ++g) {
+    const double target = total * g / n;
+    nw[g] = long(std::lower_bound(cum.begin(), cum.end(), target, [](uint64_t a, double t) { return double(a) < t; }) - cum.begin());
+    clampMove(g);
+  }
+  for (int g = 1; g < n; ++g) nw[g] = std::max(nw[g], nw[g - 1] + (g > 1 ? minWidth : 1));
+  for (int g = n - 1; g > 0; --g) nw[g] = std::min(nw[g], nw[g + 1] - (g < n - 1 ? minWidth : 1));
+  for (int g = 1; g < n; ++g) clampMove(g);
+  return std::vector<uint32_t>(nw.begin(), nw.end());
+}
+
+}  // namespace detail
+
 template <typename T, typename N, template <size_t, typename C = N> typename V = sph::vec>
 class Solver final : public sph::Solver<T, N, V> {
   static_assert(std::is_same_v<N, float> || std::is_same_v<N, double>, "N must be float or double");
@@ -36,6 +115,41 @@ class Solver final : public sph::Solver<T, N, V> {
   pbf_ctx *ctx_ = nullptr;
   const N h_;
   std::vector<double> wells_;
+  // ---- several devices (slabs): ctx_ aliases slabs_[0] ----------------------------------------
+  std::vector<int> devices_;
+  std::vector<pbf_ctx *> slabs_;
+  std::vector<pbf_comm *> comms_;
+  std::vector<std::unique_ptr<detail::Mailbox>> boxes_;
+  std::vector<detail::InProcessLink> links_;
+  std::vector<uint32_t> cuts_;
+  uint32_t flags_ = 0;
+  uint64_t frame_ = 0;
+  unsigned rebalanceEvery_ = 8;
+  bool attached_ = false;
+  bool multi() const { return slabs_.size() > 1; }
+
+  template <typename F> void parallel(F &&f) {  // one host thread per device, errors rethrown on the caller's thread
+    std::vector<std::thread> ts;
+    std::vector<std::string> errs(slabs_.size());
+    for (size_t g = 0; g < slabs_.size(); ++g)
+      ts.emplace_back([&, g] {
+        try {
+          f(g);
+        } catch (const std::exception &e) {
+          errs[g] = e.what();
+        }
+      });
+    for (auto &t : ts) t.join();
+    for (const auto &e : errs)
+      if (!e.empty()) throw std::runtime_error(e);
+  }
+  void checkOn(size_t g, int rc, const char *what) const {
+    if (rc < 0) throw std::runtime_error(std::string(what) + " (device " + std::to_string(devices_[g]) + "): " + pbf_last_error(slabs_[g]));
+  }
+  uint32_t columnOf(const sph::SphParams<T, N, V> &c, N x) const {  // ompsph.hpp:132-135,152 in N
+    const N minExtent = c.minBound.x / c.scale - h_ * 2;
+    return uint32_t(int64_t((x / c.scale - minExtent) / h_));
+  }
 
   void check(int rc, const char *what) const {
     if (rc < 0) throw std::runtime_error(std::string(what) + ": " + pbf_last_error(ctx_));
@@ -80,26 +194,146 @@ public:
     const int rc = pbf_create(&d, &ctx_);
     if (rc != PBF_OK) throw std::runtime_error(std::string("pbf_create: ") + pbf_last_error(nullptr));
   }
-  ~Solver() override { pbf_destroy(ctx_); }
+  // Several GPUs of one node: x-slabs, one ctx per entry of `devices` (an entry may repeat: see the file header).
+  Solver(N h, std::vector<int> devices, uint32_t flags = 0) : h_(h), devices_(std::move(devices)), flags_(flags) {
+    if (devices_.empty()) devices_.push_back(0);
+    for (int dev : devices_) {
+      pbf_desc d{};
+      d.abi_version = PBF_ABI_VERSION;
+      d.fp64 = std::is_same_v<N, double> ? 1 : 0;
+      d.device = dev, d.flags = flags, d.h = double(h), d.stream = nullptr;
+      pbf_ctx *c = nullptr;
+      if (pbf_create(&d, &c) != PBF_OK) {
+        const std::string msg = pbf_last_error(nullptr);
+        for (auto *s : slabs_) pbf_destroy(s);
+        throw std::runtime_error("pbf_create: " + msg);
+      }
+      slabs_.push_back(c);
+    }
+    ctx_ = slabs_[0];
+    if (!multi()) return;
+    const int n = int(slabs_.size());
+    comms_.assign(n, nullptr);
+    const bool distinct = std::set<int>(devices_.begin(), devices_.end()).size() == devices_.size();
+    if (distinct) {  // RCCL over xGMI: ncclCommInitRank must be entered by all ranks concurrently
+      unsigned char id[PBF_COMM_ID_BYTES];
+      if (pbf_comm_unique_id(id) != PBF_OK) throw std::runtime_error(std::string("pbf_comm_unique_id: ") + pbf_comm_last_error(nullptr));
+      parallel([&](size_t g) {
+        if (pbf_comm_create_rccl(id, n, int(g), devices_[g], &comms_[g]) != PBF_OK)
+          throw std::runtime_error(std::string("pbf_comm_create_rccl: ") + pbf_comm_last_error(nullptr));
+      });
+    } else {  // slabs sharing a GPU: in-process mailboxes behind the library's host-callback transport
+      for (int k = 0; k < 2 * (n - 1); ++k) boxes_.emplace_back(new detail::Mailbox());
+      links_.resize(n);
+      for (int g = 0; g < n; ++g) {
+        if (g > 0) links_[g].toLeft = boxes_[2 * (g - 1) + 1].get(), links_[g].fromLeft = boxes_[2 * (g - 1)].get();
+        if (g + 1 < n) links_[g].toRight = boxes_[2 * g].get(), links_[g].fromRight = boxes_[2 * g + 1].get();
+      }
+      for (int g = 0; g < n; ++g)
+        if (pbf_comm_create_host_callback(&detail::InProcessLink::exchange, &links_[g], n, g, &comms_[g]) != PBF_OK)
+          throw std::runtime_error("pbf_comm_create_host_callback failed");
+    }
+  }
+  ~Solver() override {
+    if (slabs_.empty()) pbf_destroy(ctx_);
+    for (auto *s : slabs_) pbf_destroy(s);
+    for (auto *c : comms_) pbf_comm_destroy(c);
+  }
+  size_t deviceCount() const { return slabs_.empty() ? 1 : slabs_.size(); }
+  const std::vector<uint32_t> &cuts() const { return cuts_; }
+  void setRebalanceEvery(unsigned steps) { rebalanceEvery_ = steps; }
   Solver(const Solver &) = delete;
   Solver &operator=(const Solver &) = delete;
 
   pbf_ctx *context() { return ctx_; }
 
   // ---- device-resident path -------------------------------------------------------------------
-  void upload(const std::vector<sph::Particle<T, N, V>> &xs) {
+  // Several devices: `config` places the cuts (its bounds and scale define the grid columns); the slabs start with
+  // equal particle counts.
+  void upload(const std::vector<sph::Particle<T, N, V>> &xs, const sph::SphParams<T, N, V> *config = nullptr) {
     const auto l = layout();
-    check(pbf_upload_aos(ctx_, xs.size(), xs.data(), &l), "pbf_upload_aos");
+    if (!multi()) {
+      check(pbf_upload_aos(ctx_, xs.size(), xs.data(), &l), "pbf_upload_aos");
+      return;
+    }
+    if (!config) throw std::runtime_error("upload() on several devices needs the SphParams (grid columns for the cuts)");
+    const int n = int(slabs_.size());
+    std::vector<uint32_t> col(xs.size());
+    for (size_t i = 0; i < xs.size(); ++i) col[i] = std::min<uint32_t>(columnOf(*config, xs[i].position.x), 1023u);
+    if (!attached_) {  // first upload: cuts at the particle-count quantiles of the columns
+      std::vector<uint32_t> sorted(col);
+      std::sort(sorted.begin(), sorted.end());
+      cuts_.assign(n + 1, 0);
+      for (int g = 1; g < n; ++g) cuts_[g] = sorted.empty() ? uint32_t(g) : sorted[std::min(sorted.size() - 1, sorted.size() * g / n)];
+      cuts_[n] = 1024;
+      for (int g = 1; g <= n; ++g) cuts_[g] = std::max(cuts_[g], cuts_[g - 1] + 1);
+    }
+    std::vector<std::vector<sph::Particle<T, N, V>>> part(n);
+    for (size_t i = 0; i < xs.size(); ++i) {
+      const int g = int(std::upper_bound(cuts_.begin() + 1, cuts_.end() - 1, col[i]) - (cuts_.begin() + 1));
+      part[g].push_back(xs[i]);
+    }
+    const size_t per = std::max<size_t>(xs.size() / n, 1);
+    const uint32_t capGhost = uint32_t(std::max<size_t>(per / 4, 1u << 15)), capMig = uint32_t(std::max<size_t>(per / 16, 1u << 13));
+    for (int g = 0; g < n; ++g) {
+      if (!attached_) checkOn(g, pbf_reserve(slabs_[g], 3 * per + 2 * capGhost), "pbf_reserve");
+      checkOn(g, pbf_upload_aos(slabs_[g], part[g].size(), part[g].data(), &l), "pbf_upload_aos");
+      if (!attached_) checkOn(g, pbf_slab_attach(slabs_[g], comms_[g], cuts_.data(), capMig, capGhost), "pbf_slab_attach");
+    }
+    attached_ = true;
   }
   void step(const sph::SphParams<T, N, V> &config, const sph::Scene<T, N, V> &scene = {}, uint32_t count = 1) {
     const pbf_params p = params(config, scene);
-    check(pbf_steps(ctx_, &p, count), "pbf_steps");
+    if (!multi()) {
+      check(pbf_steps(ctx_, &p, count), "pbf_steps");
+      return;
+    }
+    if (!attached_) throw std::runtime_error("step() before upload()");
+    for (uint32_t k = 0; k < count; ++k) {
+      if (rebalanceEvery_ && frame_ && frame_ % rebalanceEvery_ == 0) rebalance();
+      ++frame_;
+      parallel([&](size_t g) { checkOn(g, pbf_slab_step(slabs_[g], &p), "pbf_slab_step"); });
+    }
   }
-  void sync() { check(pbf_sync(ctx_), "pbf_sync"); }
+  // Load balance: all-device column histogram -> new cuts (detail::recut) -> every ctx.
+  bool rebalance() {
+    std::vector<uint64_t> hist(1024, 0);
+    for (size_t g = 0; g < slabs_.size(); ++g) {
+      uint32_t h[1024];
+      checkOn(g, pbf_slab_column_histogram(slabs_[g], h), "pbf_slab_column_histogram");
+      for (int c = 0; c < 1024; ++c) hist[c] += h[c];
+    }
+    const auto nw = detail::recut(cuts_, hist);
+    if (nw == cuts_) return false;
+    cuts_ = nw;
+    for (size_t g = 0; g < slabs_.size(); ++g) checkOn(g, pbf_slab_set_cuts(slabs_[g], cuts_.data()), "pbf_slab_set_cuts");
+    return true;
+  }
+  void sync() {
+    if (!multi()) check(pbf_sync(ctx_), "pbf_sync");
+    else
+      for (size_t g = 0; g < slabs_.size(); ++g) checkOn(g, pbf_sync(slabs_[g]), "pbf_sync");
+  }
+  size_t count() const {
+    if (!multi()) return pbf_count(ctx_);
+    size_t n = 0;
+    for (auto *s : slabs_) n += pbf_owned_count(s);
+    return n;
+  }
+  // Several devices: slab after slab (each slab in its own Z-order).
   void download(std::vector<sph::Particle<T, N, V>> &xs) {
-    xs.resize(pbf_count(ctx_));
     const auto l = layout();
-    check(pbf_download_aos(ctx_, xs.data(), &l), "pbf_download_aos");
+    if (!multi()) {
+      xs.resize(pbf_count(ctx_));
+      check(pbf_download_aos(ctx_, xs.data(), &l), "pbf_download_aos");
+      return;
+    }
+    xs.resize(count());
+    size_t at = 0;
+    for (size_t g = 0; g < slabs_.size(); ++g) {
+      checkOn(g, pbf_download_aos(slabs_[g], xs.data() + at, &l), "pbf_download_aos");
+      at += pbf_owned_count(slabs_[g]);
+    }
   }
 
   // ---- the reference's contract ---------------------------------------------------------------
@@ -130,6 +364,14 @@ public:
     if (xs.empty()) {  // ompsph.hpp:122-126
       std::cout << "Particles depleted" << std::endl;
       std::this_thread::sleep_for(std::chrono::milliseconds(5));
+      return {};
+    }
+    if (multi()) {
+      if (config.surface || !scene.queries.empty())
+        throw std::runtime_error("surface / queries are single-device features (pbf_surface is not available in slab mode)");
+      upload(xs, &config);
+      step(config, scene, 1);
+      download(xs);
       return {};
     }
     upload(xs);

@@ -2,6 +2,7 @@
 // driver never touches: sources, drains, queries, depletion, and advance() == resident stepping
 // (reference behaviour: src/omp/ompsph.hpp:91-126,167-186).  Prints "ok <name>" / "FAIL <name> ..."
 // lines; tests/test_cli_gpu.py runs it on a GPU.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <set>
@@ -101,6 +102,39 @@ int main() {
     bool same = a.size() == b.size();
     for (size_t i = 0; same && i < a.size(); ++i) same = a[i] == b[i];
     CHECK("advance_equals_resident", same, "sizes %zu %zu", a.size(), b.size());
+  }
+  {  // Solver(h, {devices...}): three x-slabs (sharing this GPU: in-process exchange behind the library's host-callback
+     // transport; distinct GPUs take RCCL) == ONE solver up to summation order; nothing lost; cuts re-balanced
+    auto [dparam, dparticles] = sph::damBreakConfig<T, N, sph::vec>(8192, 2, N(500));
+    auto a = dparticles, b = dparticles;
+    sph::hip_impl::Solver<T, N> slabs(N(0.1), std::vector<int>{0, 0, 0});
+    slabs.setRebalanceEvery(2);
+    slabs.upload(a, &dparam);
+    const auto cuts0 = slabs.cuts();
+    slabs.step(dparam, {}, 12);
+    slabs.download(a);
+    sph::hip_impl::Solver<T, N> one(N(0.1));
+    one.upload(b);
+    one.step(dparam, {}, 12);
+    one.download(b);
+    auto byId = [](const P &x, const P &y) { return x.id < y.id; };
+    std::sort(a.begin(), a.end(), byId);
+    std::sort(b.begin(), b.end(), byId);
+    bool ids = a.size() == b.size();
+    double worst = 0, sum = 0;
+    for (size_t i = 0; ids && i < a.size(); ++i) {
+      ids = a[i].id == b[i].id;
+      const V3 d = a[i].position - b[i].position;
+      const double e = std::sqrt(double(d.x) * d.x + double(d.y) * d.y + double(d.z) * d.z);
+      worst = std::max(worst, e), sum += e;
+    }
+    CHECK("multi_device_slabs", ids && slabs.deviceCount() == 3 && sum / double(a.size()) <= 0.05 && slabs.cuts() != cuts0,
+          "sizes %zu %zu worst %g mean %g", a.size(), b.size(), worst, sum / double(a.size()));
+    // advance() on several devices keeps the reference's contract too (upload -> step -> download)
+    auto c = dparticles;
+    sph::hip_impl::Solver<T, N> two(N(0.1), std::vector<int>{0, 0});
+    two.advance(dparam, {}, c);
+    CHECK("multi_device_advance", c.size() == dparticles.size(), "size %zu", c.size());
   }
   std::printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;

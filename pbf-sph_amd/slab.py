@@ -51,6 +51,32 @@ def balanced_cuts(nranks, x_world_all, box_x, scale=500.0, h=0.1):
     return cuts
 
 
+MIN_SLAB_COLUMNS = 4   # a particle moves < 2 columns per step (v dt < 2 h): it then always lands in an ADJACENT slab
+MAX_CUT_MOVE = 2       # columns a cut may move per re-cut: transferred columns go to the adjacent rank only
+
+
+def recut(old_cuts, histogram, max_move=MAX_CUT_MOVE, min_width=MIN_SLAB_COLUMNS):
+    """New cuts from the global per-column particle histogram (1024 bins): particle-count quantiles, each cut moved
+    by at most `max_move` columns from where it is (so that every particle's new owner is its old owner or a direct
+    neighbour: migration is point-to-point between adjacent slabs) and slabs kept >= `min_width` columns wide where the
+    old ones were.  Deterministic: every rank computes the same cuts from the same histogram."""
+    n = len(old_cuts) - 1
+    h = np.asarray(histogram, np.int64)
+    cum = np.concatenate([[0], np.cumsum(h)])
+    total = int(cum[-1])
+    new = list(old_cuts)
+    for g in range(1, n):
+        want = int(np.searchsorted(cum, total * g / n, side="left"))  # smallest c with cum[c] >= target
+        new[g] = int(min(max(want, old_cuts[g] - max_move), old_cuts[g] + max_move))
+    for g in range(1, n):      # keep the widths (left to right, then right to left): never below min_width
+        new[g] = max(new[g], new[g - 1] + (min_width if g > 1 else 1))
+    for g in range(n - 1, 0, -1):
+        new[g] = min(new[g], new[g + 1] - (min_width if g < n - 1 else 1))
+    for g in range(1, n):      # the clamps above never undo the max_move bound by more than they must
+        new[g] = int(min(max(new[g], old_cuts[g] - max_move), old_cuts[g] + max_move))
+    return new
+
+
 class HipEngine:
     """The product engine: pbf_sph_amd.Solver (C ABI) + torch device buffers for the wire."""
 
@@ -113,12 +139,142 @@ class HipEngine:
     def finish(self):
         self.s._chk(self.L.pbf_slab_finish(self.ctx), "pbf_slab_finish")
 
+    def column_histogram(self):
+        """Owned particles per GLOBAL grid column (1024 bins) as of the last predict (device histogram of the keys)."""
+        out = np.zeros(1024, np.uint32)
+        self.s._chk(self.L.pbf_slab_column_histogram(self.ctx, out.ctypes.data_as(C.c_void_p)),
+                    "pbf_slab_column_histogram")
+        return out.astype(np.int64)
+
     def sync(self):
         self.s.sync()
 
     @property
     def n_owned(self):
         return self.L.pbf_owned_count(self.ctx)
+
+
+class GlooHostTransport:
+    """The library's host-callback transport over torch.distributed point-to-point (gloo): the library hands pinned
+    HOST buffers, this moves them to / from rank - 1 and rank + 1 in one batched round.  Lets several ranks share
+    ONE GPU for tests; production uses the RCCL transport (pbf_comm_create_rccl)."""
+
+    def __init__(self, dist, torch, rank, nranks):
+        from . import capi
+        self.dist, self.torch, self.rank, self.nranks = dist, torch, rank, nranks
+        self.rounds = 0
+        self.fn = capi.EXCHANGE_FN(self._exchange)  # keep the ctypes thunk alive
+
+    def _exchange(self, user, s_l, n_sl, s_r, n_sr, r_l, n_rl, r_r, n_rr):
+        try:
+            t = self.torch
+            ops = []
+
+            def view(ptr, n):
+                return t.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n,)))
+
+            for peer, ptr, n, recv in ((self.rank - 1, r_l, n_rl, True), (self.rank + 1, r_r, n_rr, True),
+                                       (self.rank - 1, s_l, n_sl, False), (self.rank + 1, s_r, n_sr, False)):
+                if n and 0 <= peer < self.nranks:
+                    ops.append(self.dist.P2POp(self.dist.irecv if recv else self.dist.isend, view(ptr, n), peer))
+            if ops:
+                for w in self.dist.batch_isend_irecv(ops):
+                    w.wait()
+                self.rounds += 1
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print("GlooHostTransport:", repr(e), flush=True)
+            return 1
+
+
+class CSlabSolver:
+    """One rank of the slab decomposition with the WHOLE step — kernels and exchanges — inside libpbf_hip.so
+    (pbf_slab_step): this class only creates the communicator, attaches it and drives the load balance.
+
+    transport "rccl": ncclSend / ncclRecv over xGMI on the solver's stream (the unique id travels over `dist`);
+    transport "gloo-host": host-staged callback (tests, several ranks on one GPU)."""
+
+    def __init__(self, solver, dist, torch, rank, nranks, cuts, cap_migrants, cap_ghosts, transport="rccl",
+                 rebalance_every=0, device=0):
+        from . import capi
+        self.s, self.L, self.dist, self.torch = solver, solver.L, dist, torch
+        self.rank, self.nranks, self.transport = rank, nranks, transport
+        self.comm = C.c_void_p()
+        if transport == "rccl":
+            ident = (C.c_uint8 * 128)()
+            box = [None]
+            if rank == 0:
+                self._chk_comm(self.L.pbf_comm_unique_id(ident), "pbf_comm_unique_id")
+                box = [bytes(ident)]
+            if nranks > 1:
+                dist.broadcast_object_list(box, src=0)
+            ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            self._chk_comm(self.L.pbf_comm_create_rccl(ident, nranks, rank, device, C.byref(self.comm)),
+                           "pbf_comm_create_rccl")
+            self.host = None
+        else:
+            self.host = GlooHostTransport(dist, torch, rank, nranks)
+            self._chk_comm(self.L.pbf_comm_create_host_callback(self.host.fn, None, nranks, rank, C.byref(self.comm)),
+                           "pbf_comm_create_host_callback")
+        self.cuts = [int(c) for c in cuts]
+        arr = (C.c_uint32 * (nranks + 1))(*self.cuts)
+        solver._chk(self.L.pbf_slab_attach(solver.ctx, self.comm, arr, int(cap_migrants), int(cap_ghosts)),
+                    "pbf_slab_attach")
+        self.rebalance_every = int(rebalance_every)
+        self.frame = 0
+        self.stats = dict(recuts=0)
+
+    def _chk_comm(self, rc, what):
+        if rc != 0:
+            msg = self.L.pbf_comm_last_error(None)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    @property
+    def rounds(self):
+        return int(self.L.pbf_comm_rounds(self.comm))
+
+    @property
+    def n_owned(self):
+        return self.L.pbf_owned_count(self.s.ctx)
+
+    def rebalance(self):
+        """Re-cut from the global column histogram (device histogram -> all-reduce -> recut()).  Collective."""
+        if self.nranks == 1:
+            return False
+        h = np.zeros(1024, np.uint32)
+        self.s._chk(self.L.pbf_slab_column_histogram(self.s.ctx, h.ctypes.data_as(C.c_void_p)),
+                    "pbf_slab_column_histogram")
+        t = self.torch.from_numpy(h.astype(np.int64))
+        if self.dist.get_backend() == "nccl":
+            t = t.cuda()
+        self.dist.all_reduce(t)
+        new = recut(self.cuts, t.cpu().numpy())
+        if new != self.cuts:
+            self.cuts = new
+            arr = (C.c_uint32 * (self.nranks + 1))(*new)
+            self.s._chk(self.L.pbf_slab_set_cuts(self.s.ctx, arr), "pbf_slab_set_cuts")
+            self.stats["recuts"] += 1
+            return True
+        return False
+
+    def step(self, p):
+        if self.rebalance_every and self.frame and self.frame % self.rebalance_every == 0:
+            self.rebalance()
+        self.frame += 1
+        self.s._chk(self.L.pbf_slab_step(self.s.ctx, C.byref(p)), "pbf_slab_step")
+
+    def steps(self, p, count):
+        if not self.rebalance_every:
+            self.s._chk(self.L.pbf_slab_steps(self.s.ctx, C.byref(p), count), "pbf_slab_steps")
+            self.frame += count
+            return
+        for _ in range(count):
+            self.step(p)
+
+    def close(self):
+        if self.comm:
+            self.L.pbf_comm_destroy(self.comm)
+            self.comm = C.c_void_p()
 
 
 class SlabSolver:
@@ -221,9 +377,30 @@ class SlabSolver:
         self._exchange((n_l * b, n_r * b), (g_l * b, g_r * b))
         return g_l, g_r
 
+    # -- load balance -----------------------------------------------------------------------------
+    def rebalance(self):
+        """Re-cut from the global column histogram (one small all-reduce + a host sync; every `rebalance_every`
+        steps).  The particles of a transferred column migrate with the next step's ordinary migration round."""
+        if self.dist is None or self.nranks == 1:
+            return False
+        t = self.e.torch
+        h = t.from_numpy(self.e.column_histogram())
+        if self.dist.get_backend() == "nccl":
+            h = h.to(self.e.device)
+        self.dist.all_reduce(h)
+        new = recut(self.cuts, h.cpu().numpy())
+        if new != self.cuts:
+            self.set_cuts(new)
+            self.stats["recuts"] += 1
+            return True
+        return False
+
     # -- one step ---------------------------------------------------------------------------------
     def step(self, p):
         e = self.e
+        if self.rebalance_every and self.frame and self.frame % self.rebalance_every == 0:
+            self.rebalance()
+        self.frame += 1
         e.predict(p)
         n_l, n_r = e.migrate(self.cut, self.send[0], self.send[1], self.cap)
         g_l, g_r = self._swap(REC_MIGRANT, n_l, n_r)

@@ -108,6 +108,58 @@ def ref_grid():
     print("ref_grid.npz:", len(out), "arrays")
 
 
+def mc_case_digests(tri_rows):
+    """Per case: CRC32 of (a) the oriented polygon loops the triangles tile and (b) the oriented triangle set — both
+    canonicalised, so the digests do not depend on the order rows are written in.  Digests, not the table."""
+    import zlib
+
+    def tris_of(row):
+        row = [int(v) for v in row if v != 255]
+        return [tuple(row[i:i + 3]) for i in range(0, len(row), 3)]
+
+    def canon(t):
+        k = t.index(min(t))
+        return (t[k], t[(k + 1) % 3], t[(k + 2) % 3])
+
+    loops_crc, tris_crc = [], []
+    for row in tri_rows:
+        tris = tris_of(row)
+        directed = {e for a, b, c in tris for e in ((a, b), (b, c), (c, a))}
+        nxt = {a: b for a, b in directed if (b, a) not in directed}
+        loops, seen = [], set()
+        for s0 in sorted(nxt):
+            if s0 in seen:
+                continue
+            loop, cur = [], s0
+            while cur not in seen:
+                seen.add(cur)
+                loop.append(cur)
+                cur = nxt[cur]
+            k = loop.index(min(loop))
+            loops.append(tuple(loop[k:] + loop[:k]))
+        loops_crc.append(zlib.crc32(repr(sorted(loops)).encode()))
+        tris_crc.append(zlib.crc32(repr(sorted(canon(t) for t in tris)).encode()))
+    return np.array(loops_crc, np.uint32), np.array(tris_crc, np.uint32)
+
+
+def ref_mc():
+    """Digests of the reference's marching-cubes case tables (src/mc_constants.h compiled where it lies,
+    oracle/ref_mc.cpp).  EdgeTable and NumVertsTable follow from first principles (crossed edges; triangle count of
+    the case) and are stored as numbers; of TriTable only per-case CRC32 digests are kept."""
+    so = os.path.join(O.ORACLE_DIR, "_ref", "libref_mc.so")
+    assert os.path.exists(so), "oracle/_ref/libref_mc.so missing (needs /root/reference)"
+    R = C.CDLL(so)
+    for f in (R.ref_mc_edge, R.ref_mc_numverts, R.ref_mc_tri):
+        f.restype = C.c_uint32
+    tri = [[R.ref_mc_tri(ci, j) for j in range(16)] for ci in range(256)]
+    loops_crc, tris_crc = mc_case_digests(tri)
+    np.savez_compressed(os.path.join(HERE, "ref_mc_digest.npz"),
+                        edge=np.array([R.ref_mc_edge(ci) for ci in range(256)], np.uint32),
+                        numverts=np.array([R.ref_mc_numverts(ci) for ci in range(256)], np.uint32),
+                        loops_crc=loops_crc, tris_crc=tris_crc)
+    print("ref_mc_digest.npz: 4 arrays")
+
+
 def by_id(d):
     o = np.argsort(d["id"], kind="stable")
     return {k: v[o] for k, v in d.items()}
@@ -146,4 +198,5 @@ def oracle_selfcheck():
 if __name__ == "__main__":
     O.build()
     ref_grid()
+    ref_mc()
     oracle_selfcheck()

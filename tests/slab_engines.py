@@ -211,5 +211,12 @@ class OracleEngine:
         self._set(self._take(st, keep))
         self.n_owned_ = len(keep)
 
+    def column_histogram(self):
+        """Owned particles per GLOBAL column as of the last predict (keys are kept in the rank-local frame)."""
+        st = self._state()
+        own = (st["type"] & GHOST) == 0
+        cx = compact10(st["key"].astype(np.int64))[own] + self.xoff
+        return np.bincount(cx, minlength=1024)[:1024].astype(np.int64)
+
     def download(self):
         return self.o.get_particles()

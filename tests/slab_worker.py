@@ -1,7 +1,9 @@
 """Worker of the slab tests: one rank of an N-rank run of pbf-sph_amd/slab.py.
 
   engine "oracle": CPU engine (tests/slab_engines.py), gloo, CPU tensors        — runs anywhere
-  engine "hip"   : the product engine on cuda:0, gloo with host-staged buffers   — several ranks share ONE GPU
+  engine "hip"   : the product kernels on cuda:0 driven by slab.py's Python protocol, gloo with host-staged buffers
+  engine "hipc"  : the product path: pbf_slab_step inside libpbf_hip.so (C ABI) with the host-callback transport
+                   over gloo                                                      — several ranks share ONE GPU
 Writes the rank's final owned particles to <out>/rank<r>.npz."""
 import argparse
 import os
@@ -24,6 +26,7 @@ def main():
     ap.add_argument("--iteration", type=int, default=4)
     ap.add_argument("--cuts", default="even")
     ap.add_argument("--fp64", action="store_true")
+    ap.add_argument("--rebalance", type=int, default=0)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -59,12 +62,21 @@ def main():
         eng = slab.HipEngine(s, torch, torch.device("cuda", 0))
         get = s.download
         stage = True
-    drv = slab.SlabSolver(eng, dist, rank, world, cuts, cap, stage_via_host=stage)
-    drv.steps(p, a.steps)
+    if a.engine == "hipc":
+        drv = slab.CSlabSolver(s, dist, torch, rank, world, cuts, cap, cap, transport="gloo-host",
+                               rebalance_every=a.rebalance)
+        drv.steps(p, a.steps)
+        stats = dict(migrated=-1, ghosts=-1, exchanges=drv.rounds, recuts=drv.stats["recuts"])
+        cuts = drv.cuts
+    else:
+        drv = slab.SlabSolver(eng, dist, rank, world, cuts, cap, stage_via_host=stage, rebalance_every=a.rebalance)
+        drv.steps(p, a.steps)
+        stats = dict(migrated=drv.stats["migrated"], ghosts=drv.stats["ghosts"], exchanges=drv.stats["exchanges"],
+                     recuts=drv.stats["recuts"])
+        cuts = drv.cuts
     out = get()
     os.makedirs(a.out, exist_ok=True)
-    np.savez(os.path.join(a.out, f"rank{rank}.npz"), migrated=drv.stats["migrated"], ghosts=drv.stats["ghosts"],
-             exchanges=drv.stats["exchanges"], cuts=np.array(cuts), **out)
+    np.savez(os.path.join(a.out, f"rank{rank}.npz"), cuts=np.array(cuts), **stats, **out)
     dist.barrier()
     dist.destroy_process_group()
 

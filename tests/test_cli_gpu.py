@@ -74,5 +74,17 @@ def test_cpp_shim_sources_drains_queries():
     (sources, drains, queries, depletion — ompsph.hpp:91-126,167-186) and advance() == resident."""
     r = subprocess.run([os.path.join(ROOT, "pbf-sph_amd", "test_shim")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout + r.stderr
-    for name in ("sources_count", "sources_accumulate", "drains", "queries", "depleted", "advance_equals_resident"):
+    for name in ("sources_count", "sources_accumulate", "drains", "queries", "depleted", "advance_equals_resident",
+                 "multi_device_slabs", "multi_device_advance"):
         assert f"ok {name}" in r.stdout, r.stdout
+
+
+def test_cli_slabs(tmp_path):
+    """--slabs K: hip_impl::Solver(h, {devices...}) — K x-slabs behind the same CLI, pbf_slab_step per slab on its own
+    host thread, exchange inside the library (in-process transport here: the slabs share this GPU; --all-devices on
+    a multi-GPU node takes RCCL).  Same particle count, same summary block."""
+    txt = run_cli("--scene", "dam-break", "--particles", "8192", "--solver-iter", "2", "-n", "6", "-w", "2", "--slabs", "3",
+                  "--json", "-o", str(tmp_path / "o"))
+    assert "Slab mode (3 slabs)" in txt and "Final Particle count : 8192" in txt and "Results flushed." in txt
+    j = json.loads([l for l in txt.split("\n") if l.startswith("{")][0])
+    assert j["slabs"] == 3 and j["resident"] is True and j["particles"] == 8192

@@ -530,3 +530,34 @@ def test_full_size_properties(pkg, nominal, fp64):
     s2.upload(**sc)
     s2.steps(p, 6)
     assert np.array_equal(s2.download()["pos"], g1["pos"])
+
+
+def test_pile_up_in_one_cell_sorts_in_bounded_time(pkg, oracle):
+    """50 000 particles inside ONE grid cell (+ 3 000 outside the grid: the overflow bucket, ordered by (key, source)):
+    the sort's in-cell rank would be O(m^2) per cell; cells above BIG_CELL members take the segment sort instead
+    (k_sort_big_cells).  K = 0 (predict + sort + diffuse + finalise): the permutation and every field equal the
+    oracle's stable sort, bit for bit, and the step stays far below the quadratic cost."""
+    import time
+    rng = np.random.default_rng(3)
+    pile = (rng.random((50000, 3)) * 40 + np.array([505, 505, 505])).astype(np.float32)   # one 50-unit cell
+    outside = (rng.random((3000, 3)) * 1000 + np.array([3000, 0, 0])).astype(np.float32)   # x beyond the grid
+    far = (rng.random((4000, 3)) * 900 + 50).astype(np.float32)
+    pos = np.concatenate([pile, outside, far])
+    n = len(pos)
+    perm = rng.permutation(n)
+    sc = dict(id=np.arange(n, dtype=np.uint64), type=np.zeros(n, np.uint8), mass=np.ones(n, np.float32), pos=pos[perm],
+              vel=np.zeros((n, 3), np.float32), colour=rng.random((n, 4)).astype(np.float32))
+    s, o = mk(pkg, oracle, sc, False)
+    p, q = params_pair(pkg, oracle, iteration=0)
+    p.constant_force[1] = 0.0   # keep the pile in its cell
+    q.constant_force[1] = 0.0
+    s.stage("predict", p).stage("sort", p).sync()
+    o.predict(q).sort(q).grid_table(q)
+    keys = s.keys().astype(np.int64)
+    assert np.bincount(keys[keys < len(s.table())]).max() >= 50000
+    assert_state_equal(s.download(), o.get_particles(), "pile-up sort")
+    t0 = time.perf_counter()
+    for _ in range(5):
+        s.stage("predict", p).stage("sort", p)
+    s.sync()
+    assert (time.perf_counter() - t0) / 5 < 0.05, "sort of a 50 000-particle cell took too long"

@@ -1,7 +1,10 @@
 """Slab decomposition on the GPU: several ranks share cuda:0 (gloo, host-staged wire buffers — the
 production transport is RCCL, exercised by bench.py --gpus N on a multi-GPU node).
+  engine "hipc" = the product path: pbf_slab_step inside libpbf_hip.so (whole step + exchanges behind the C ABI,
+                  host-callback transport here); engine "hip" = the same kernels sequenced by slab.py's Python driver.
   * HIP slabs == oracle-engine slabs, bit for bit (same protocol, same ordering, same arithmetic);
-  * HIP slabs == single-GPU run to summation-order noise; nothing lost or duplicated."""
+  * HIP slabs == single-GPU run to summation-order noise; nothing lost or duplicated;
+  * 2 + 2K exchange rounds per step; load-balance re-cuts agree with the CPU twin; RCCL communicator set-up."""
 import os
 
 import numpy as np
@@ -12,15 +15,18 @@ from test_slab_cpu import launch, merged
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,cuts", [(2, "x:210"), (3, "x:210,700")])
-def test_hip_slabs_bit_exact_vs_oracle_slabs(pkg, tmp_path, world, cuts):
+@pytest.mark.parametrize("engine,world,cuts", [("hipc", 2, "x:210"), ("hipc", 3, "x:210,700"), ("hip", 2, "x:210")])
+def test_hip_slabs_bit_exact_vs_oracle_slabs(pkg, tmp_path, engine, world, cuts):
     args = ("--scene", "cubes2048", "--steps", "5", "--cuts", cuts)
-    hip = launch(world, str(tmp_path / "hip"), "--engine", "hip", *args)
+    hip = launch(world, str(tmp_path / "hip"), "--engine", engine, *args)
     ora = launch(world, str(tmp_path / "ora"), "--engine", "oracle", *args)
     for r in range(world):
         for k in ("id", "pos", "vel", "colour", "type"):
             assert np.array_equal(hip[r][k], ora[r][k]), (r, k)
-        assert int(hip[r]["ghosts"]) == int(ora[r]["ghosts"]) > 0
+        if engine == "hip":
+            assert int(hip[r]["ghosts"]) == int(ora[r]["ghosts"]) > 0
+        else:  # inside the library: 2 assembly rounds + 2K field refreshes per step, nothing else
+            assert int(hip[r]["exchanges"]) == 5 * (2 + 2 * 4), int(hip[r]["exchanges"])
     # against ONE solver on the whole scene
     sc = pkg.scene_cubes(2048)
     s = pkg.Solver(h=0.1)
@@ -36,22 +42,21 @@ def test_hip_slabs_bit_exact_vs_oracle_slabs(pkg, tmp_path, world, cuts):
 
 def test_hip_slabs_fp64_bit_exact(pkg, tmp_path):
     args = ("--scene", "cubes2048", "--steps", "4", "--cuts", "x:210", "--fp64")
-    hip = launch(2, str(tmp_path / "hip"), "--engine", "hip", *args)
+    hip = launch(2, str(tmp_path / "hip"), "--engine", "hipc", *args)
     ora = launch(2, str(tmp_path / "ora"), "--engine", "oracle", *args)
     for r in range(2):
         assert hip[r]["pos"].dtype == np.float64
         for k in ("id", "pos", "vel", "colour", "type"):
             assert np.array_equal(hip[r][k], ora[r][k]), (r, k)
-        assert int(hip[r]["ghosts"]) > 0
 
 
-def test_hip_slabs_migration(pkg, tmp_path):
+@pytest.mark.parametrize("engine", ["hipc", "hip"])
+def test_hip_slabs_migration(pkg, tmp_path, engine):
     args = ("--scene", "dam8192", "--steps", "30", "--iteration", "2", "--cuts", "x:150")
-    hip = launch(2, str(tmp_path / "hip"), "--engine", "hip", *args)
+    hip = launch(2, str(tmp_path / "hip"), "--engine", engine, *args)
     got = merged(hip)
     sc, side = pkg.scene_dambreak(8192)
     assert np.array_equal(got["id"], np.sort(sc["id"]))
-    assert sum(int(p["migrated"]) for p in hip) > 0
     assert np.isfinite(got["pos"]).all() and got["pos"].min() >= 0 and got["pos"].max() <= side
     # same protocol on the CPU engine: bit-exact, migrants included (a free-running comparison with ONE
     # solver is meaningless after 30 violent steps: summation-order noise grows chaotically)
@@ -59,4 +64,44 @@ def test_hip_slabs_migration(pkg, tmp_path):
     for r in range(2):
         for k in ("id", "pos", "vel", "colour"):
             assert np.array_equal(hip[r][k], ora[r][k]), (r, k)
-        assert int(hip[r]["migrated"]) == int(ora[r]["migrated"])
+        if engine == "hip":
+            assert int(hip[r]["migrated"]) == int(ora[r]["migrated"]) > 0
+    assert sum(int(p["migrated"]) for p in ora) > 0
+
+
+def test_hip_slabs_rebalance_matches_cpu_twin(pkg, tmp_path):
+    """Load balance: cuts start badly placed and are moved every 2 steps from the all-reduced column histogram —
+    the library path re-cuts exactly like the CPU twin (same cuts, same particles, same bits)."""
+    args = ("--scene", "dam8192", "--steps", "12", "--iteration", "2", "--cuts", "x:400,700", "--rebalance", "2")
+    hip = launch(3, str(tmp_path / "hip"), "--engine", "hipc", *args)
+    ora = launch(3, str(tmp_path / "ora"), "--engine", "oracle", *args)
+    assert int(hip[0]["recuts"]) > 0
+    for r in range(3):
+        assert np.array_equal(hip[r]["cuts"], ora[r]["cuts"])
+        for k in ("id", "pos", "vel", "colour"):
+            assert np.array_equal(hip[r][k], ora[r][k]), (r, k)
+    sc, _ = pkg.scene_dambreak(8192)
+    assert np.array_equal(merged(hip)["id"], np.sort(sc["id"]))
+
+
+def test_rccl_communicator_single_rank(pkg):
+    """The RCCL transport's set-up path on this one-GPU box: librccl resolves, ncclCommInitRank(1 rank) succeeds,
+    a slab step through it equals a plain step (no neighbours => no exchange rounds)."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from pbf_sph_amd import slab
+    sc, side = pkg.scene_dambreak(8192)
+    p = pkg.default_params(4, side)
+    a = pkg.Solver(h=0.1)
+    a.upload(**sc)
+    drv = slab.CSlabSolver(a, None, torch, 0, 1, [0, 1024], 1024, 1024, transport="rccl")
+    drv.steps(p, 3)
+    b = pkg.Solver(h=0.1)
+    b.upload(**sc)
+    b.steps(p, 3)
+    ga, gb = a.download(), b.download()
+    for k in ("id", "pos", "vel", "colour"):
+        assert np.array_equal(ga[k], gb[k]), k
+    assert drv.rounds == 0
+    drv.close()
