@@ -170,11 +170,11 @@ typedef struct pbf_slab_cut {
   int32_t has_left, has_right; /* is there a rank on that side */
 } pbf_slab_cut;
 int pbf_reserve(pbf_ctx *ctx, size_t capacity); /* room for migrants + copies; call before pbf_upload */
-/* Optional, before the first step: key the particles in a rank-LOCAL x frame (origin = this slab's left ghost
- * column), so the grid table covers only the slab + ghost columns instead of Morton(global extent) — on an
+/* Optional, before the first step: key the particles in a rank-LOCAL x frame (origin = PBF_SLAB_FRAME_MARGIN columns left of this slab's first column), so the grid table covers only the slab + ghost columns instead of Morton(global extent) — on an
  * elongated N-slab box that is 2 M entries per rank instead of 138 M at N = 8.  left_xlo / right_xlo = the
  * xlo of the neighbouring slabs (0 for rank 0 / unused without that neighbour); records are re-keyed on arrival.
  * cut = NULL returns to global keys. */
+#define PBF_SLAB_FRAME_MARGIN 6u /* columns between the local frame's origin and the first owned column */
 int pbf_slab_configure(pbf_ctx *ctx, const pbf_slab_cut *cut, uint32_t left_xlo, uint32_t right_xlo);
 size_t pbf_slab_record_bytes(const pbf_ctx *ctx, int kind);
 /* after pbf_stage_predict: compact the particles that stay, pack the leavers; counts[2] = records for left / right */

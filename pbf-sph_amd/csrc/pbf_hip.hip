@@ -1213,8 +1213,14 @@ int pbf_slab_configure(pbf_ctx *ctx, const pbf_slab_cut *cut, uint32_t left_xlo,
     return PBF_OK;
   }
   if (cut->xhi <= cut->xlo) return fail(ctx, PBF_ERR_INVALID, "empty slab");
-  // frame origin = the left ghost column (one left of the first owned column); rank 0 keeps the padding columns
-  auto origin = [](uint32_t xlo, bool hasLeft) { return hasLeft && xlo > 0 ? xlo - 1u : 0u; };
+  // frame origin = PBF_SLAB_FRAME_MARGIN columns left of the first owned column (the left ghost column is the one
+  // next to it); rank 0 keeps the padding columns.  The margin keeps local x coordinates non-negative — a negative one
+  // would wrap in the 10-bit Morton field and send the particle to the wrong neighbour — for every particle this rank
+  // can hold at predict time: owned ones that moved left (< 2 columns per step) and, after a re-cut, the owners of
+  // columns just handed to the left neighbour (a cut moves by <= 2 columns).
+  auto origin = [](uint32_t xlo, bool hasLeft) {
+    return hasLeft && xlo > 0 ? xlo - std::min<uint32_t>(xlo, PBF_SLAB_FRAME_MARGIN) : 0u;
+  };
   ctx->slabCut = *cut;
   ctx->xoff = origin(cut->xlo, cut->has_left != 0);
   // a neighbour's records arrive keyed in ITS frame: x_mine = x_theirs + their_origin - my_origin

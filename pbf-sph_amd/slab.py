@@ -5,7 +5,7 @@ The reference is single-device — this layer has no counterpar
 correctness statement is "N ranks == 1 rank".  Layout: rank g owns the cell columns
 [cuts[g], cuts[g+1]) of the GLOBAL grid (every rank passes the same bounds) plus a one-cell layer of
 copies ("ghosts") of its x-neighbours' boundary columns.  Keys are kept in a rank-local x frame
-(origin = the left ghost column; records are re-keyed on arrival), so each rank's grid table covers its
+(origin = PBF_SLAB_FRAME_MARGIN columns left of the slab; records are re-keyed on arrival), so each rank's grid table covers its
 slab only — constant size under weak scaling instead of Morton(global extent).  Per step:
 
     predict ─ migrate ⇄ add_migrants ─ ghosts ⇄ add_ghosts ─ sort ─ diffuse ─

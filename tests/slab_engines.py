@@ -8,6 +8,7 @@ import oracle_lib as O
 
 REC_MIGRANT, REC_GHOST, REC_FIELD = 0, 1, 2
 GHOST = 2
+FRAME_MARGIN = 6  # PBF_SLAB_FRAME_MARGIN (include/pbf_hip.h): keeps local x >= 0 for everything a rank can hold
 
 
 def spread10(x):
@@ -62,7 +63,7 @@ class OracleEngine:
         return {REC_MIGRANT: self.mig_dt, REC_GHOST: self.gho_dt, REC_FIELD: self.fld_dt}[kind].itemsize
 
     def configure(self, cut, left_xlo, right_xlo):
-        origin = lambda xlo, has_left: xlo - 1 if has_left and xlo > 0 else 0  # noqa: E731
+        origin = lambda xlo, has_left: xlo - min(xlo, FRAME_MARGIN) if has_left and xlo > 0 else 0  # noqa: E731
         self.xoff = origin(cut[0], cut[2])
         self.shift = [origin(left_xlo, left_xlo > 0) - self.xoff, origin(right_xlo, True) - self.xoff]
 

@@ -99,17 +99,21 @@ def test_recut_moves_cuts_towards_balance_in_bounded_steps(pkg):
     assert slab.recut(seen[0], h) == slab.recut(list(seen[0]), h.copy())
 
 
-def test_slabs_rebalance_cpu(oracle, pkg, tmp_path):
-    """3 ranks, cuts placed badly, re-cut every 2 steps: particles of a transferred column migrate through the
-    ordinary migration round; the union still equals the single-rank run to summation-order noise."""
+@pytest.mark.parametrize("scene,cuts", [("dam2048", "x:400,700"), ("dam8192", "balanced")])
+def test_slabs_rebalance_cpu(oracle, pkg, tmp_path, scene, cuts):
+    """3 ranks, re-cut every 2 steps: particles of a transferred column migrate through the ordinary migration
+    round; the union still equals the single-rank run to summation-order noise.  "x:400,700": cuts placed badly;
+    "balanced": particle-count quantiles of the start column = slabs only TWO columns wide, cuts moving through
+    the fluid, particles crossing > 1 column per step in the lattice blow-up (this is what bench.py's strong
+    scaling does; it needs the local key frame's margin, PBF_SLAB_FRAME_MARGIN)."""
     steps = 12
-    parts = launch(3, str(tmp_path), "--engine", "oracle", "--scene", "dam2048", "--steps", str(steps), "--iteration", "2",
-                   "--cuts", "x:400,700", "--rebalance", "2")
+    parts = launch(3, str(tmp_path), "--engine", "oracle", "--scene", scene, "--steps", str(steps), "--iteration", "2",
+                   "--cuts", cuts, "--rebalance", "2")
     assert int(parts[0]["recuts"]) > 0
     assert all(np.array_equal(parts[0]["cuts"], p["cuts"]) for p in parts)       # every rank agrees on the cuts
     assert not np.array_equal(parts[0]["cuts"], [0, 10, 16, 1024])               # and they moved
     got = merged(parts)
-    sc, side = pkg.scene_dambreak(2048)
+    sc, side = pkg.scene_dambreak(int(scene[3:]))
     assert np.array_equal(got["id"], np.sort(sc["id"]))
     o = oracle.Oracle(False, device_pow=True)
     o.set_particles(**sc)

@@ -84,24 +84,43 @@ def test_hip_slabs_rebalance_matches_cpu_twin(pkg, tmp_path):
     assert np.array_equal(merged(hip)["id"], np.sort(sc["id"]))
 
 
-def test_rccl_communicator_single_rank(pkg):
-    """The RCCL transport's set-up path on this one-GPU box: librccl resolves, ncclCommInitRank(1 rank) succeeds,
-    a slab step through it equals a plain step (no neighbours => no exchange rounds)."""
-    import ctypes as C
-    import torch
-    import torch.distributed as dist
-    from pbf_sph_amd import slab
-    sc, side = pkg.scene_dambreak(8192)
-    p = pkg.default_params(4, side)
-    a = pkg.Solver(h=0.1)
-    a.upload(**sc)
-    drv = slab.CSlabSolver(a, None, torch, 0, 1, [0, 1024], 1024, 1024, transport="rccl")
-    drv.steps(p, 3)
-    b = pkg.Solver(h=0.1)
-    b.upload(**sc)
-    b.steps(p, 3)
-    ga, gb = a.download(), b.download()
-    for k in ("id", "pos", "vel", "colour"):
-        assert np.array_equal(ga[k], gb[k]), k
-    assert drv.rounds == 0
-    drv.close()
+RCCL_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+if {torch_first}:
+    import torch            # like bench.py: PyTorch (its bundled HIP runtime and librccl) is in the process first
+    torch.zeros(1, device="cuda")
+import numpy as np
+from conftest import load_package
+pkg = load_package()
+from pbf_sph_amd import slab
+sc, side = pkg.scene_dambreak(8192)
+p = pkg.default_params(4, side)
+a = pkg.Solver(h=0.1)
+a.upload(**sc)
+drv = slab.CSlabSolver(a, None, None, 0, 1, [0, 1024], 1024, 1024, transport="rccl")
+drv.steps(p, 3)
+b = pkg.Solver(h=0.1)
+b.upload(**sc)
+b.steps(p, 3)
+ga, gb = a.download(), b.download()
+assert all(np.array_equal(ga[k], gb[k]) for k in ("id", "pos", "vel", "colour"))
+assert drv.rounds == 0
+drv.close()
+print("RCCL-OK")
+"""
+
+
+@pytest.mark.parametrize("torch_first", [True, False])
+def test_rccl_communicator_single_rank(torch_first):
+    """The RCCL transport's set-up path on this one-GPU box, in a fresh process: librccl resolves (PyTorch's copy when
+    PyTorch is already in the process — bench.py's situation — else ROCm's: the C++ CLI's), ncclCommInitRank(1 rank)
+    succeeds, a slab step through it equals a plain step (no neighbours => no exchange rounds).  (Loading
+    libpbf_hip.so BEFORE PyTorch would bind PyTorch's librccl to ROCm's HIP runtime — two ROCm versions in one
+    process; bench.py imports torch first.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", RCCL_SCRIPT.format(root=root, torch_first=torch_first)], capture_output=True,
+                       text=True, timeout=600, env=dict(os.environ, NCCL_DEBUG="WARN"))
+    assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
