@@ -102,6 +102,8 @@ struct pbf_ctx {
   // otherwise the build is a launch of its own followed by a list-driven lambda: 1 = k_gather_lists build-only,
   // 2 / 3 = k_build_lists 4- / 8-way on fp pStar, 4 / 5 = k_build_lists_q (quantised pairs) 2 / 4 loads per trip
   int splitBuild = 5;
+  int coop = 0;              // option "coop": 0 = one lane per particle (bit-exact), 2 / 4 / 8 = lanes sharing a particle's
+                             // list with a wave-shuffle reduction (k_gather_from_lists_coop; rounding-level differences)
   bool cellDiffuse = true;   // option "cell_diffuse": one walk per occupied cell instead of one per particle
   bool fuseDiffuse = false;  // option "fuse_diffuse": pbf_step folds the diffuse walk into the first lambda launch
                              // (bit-identical; measured 2 % SLOWER at 1 M — the colour loads stall the filter loop — so off)
@@ -437,8 +439,20 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
   if (ctx->gatherKind == 1) {
     uint32_t *nl = ctx->nbrList.as<uint32_t>(), *nc = ctx->nbrCount.as<uint32_t>();
     const dim3 g = grid_for(ctx->n), b(BLOCK);
-    if (mode == GATHER_FROM_LISTS) {
+    auto from_lists = [&]() {  // the list-driven reader: one lane per particle, or (option "coop") a lane group per particle
+      if constexpr (Op::kTileable && Op::kFilter) {
+        auto coop_grid = [&](int k) { return dim3(unsigned(std::max<size_t>(1, (ctx->n * k + BLOCK - 1) / BLOCK))); };
+        switch (ctx->coop) {
+          case 2: hipLaunchKernelGGL((k_gather_from_lists_coop<N, Op, 2>), coop_grid(2), b, 0, ctx->stream, c, args, key, table, nl, nc); return;
+          case 4: hipLaunchKernelGGL((k_gather_from_lists_coop<N, Op, 4>), coop_grid(4), b, 0, ctx->stream, c, args, key, table, nl, nc); return;
+          case 8: hipLaunchKernelGGL((k_gather_from_lists_coop<N, Op, 8>), coop_grid(8), b, 0, ctx->stream, c, args, key, table, nl, nc); return;
+          default: break;
+        }
+      }
       hipLaunchKernelGGL((k_gather_from_lists<N, Op>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
+    };
+    if (mode == GATHER_FROM_LISTS) {
+      from_lists();
     } else if (mode == GATHER_SAVE_LISTS && ctx->splitBuild &&
                uint64_t(ctx->n) * sizeof(typename Op::Src) <= 0xFFFFFFFFull) {  // (k_build_lists: 32-bit offsets)  // build the lists, then run the op list-driven
       if (ctx->splitBuild == 1)
@@ -461,7 +475,7 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
         else
           hipLaunchKernelGGL((k_build_lists<N, 8>), g, b, 0, ctx->stream, c, Op::src(args), args.type, key, table, nl, nc);
       }
-      hipLaunchKernelGGL((k_gather_from_lists<N, Op>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
+      from_lists();
     } else if (mode == GATHER_SAVE_LISTS) {
       hipLaunchKernelGGL((k_gather_lists<N, Op, 16, true>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
     } else {
@@ -750,6 +764,10 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   else if (n == "reuse_lists") ctx->reuseLists = value != 0;
   else if (n == "fuse_diffuse") ctx->fuseDiffuse = value != 0;
   else if (n == "cell_diffuse") ctx->cellDiffuse = value != 0;
+  else if (n == "coop") {
+    if (value != 0 && value != 2 && value != 4 && value != 8) return fail(ctx, PBF_ERR_INVALID, "coop must be 0, 2, 4 or 8");
+    ctx->coop = int(value);
+  }
   else if (n == "split_build") ctx->splitBuild = int(value);
   else if (n == "timing_mask") ctx->timingMask = uint32_t(value);
   else if (n == "pad_lds") ctx->padLds = uint32_t(value);
@@ -802,6 +820,10 @@ int pbf_create(const pbf_desc *desc, pbf_ctx **out) {
   if (const char *e = std::getenv("PBF_REUSE_LISTS")) ctx->reuseLists = std::atoi(e) != 0;
   if (const char *e = std::getenv("PBF_SPLIT_BUILD")) ctx->splitBuild = std::atoi(e);
   if (const char *e = std::getenv("PBF_LIST_MAX")) ctx->listMax = uint32_t(std::atoi(e));
+  if (const char *e = std::getenv("PBF_COOP")) {
+    const int v = std::atoi(e);
+    if (v == 0 || v == 2 || v == 4 || v == 8) ctx->coop = v;
+  }
   if ((e = hipSetDevice(ctx->device)) != hipSuccess) {
     g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
     delete ctx;

@@ -1,6 +1,6 @@
 """Condense rocprofv3 CSV output into the per-round summaries kept under profiles/.
 
-  python tools/profile_summary.py kernel <dir with *_kernel_stats.csv> <out.md>
+  python tools/profile_summary.py kernel <dir with *_kernel_stats.csv> <out.md> [total_steps first_timed n_timed]
   python tools/profile_summary.py pmc <dir with *_counter_collection.csv> ... <out.md>
 """
 import glob
@@ -18,15 +18,32 @@ def short(name):
     return name.split("(")[0][:90]
 
 
-def kernel(d, out):
+def kernel(d, out, total_steps=None, first_timed=None, n_timed=None):
+    """total_steps / first_timed / n_timed (bench.py's frame plan): adds, from the kernel trace, each kernel's mean
+    duration over the dispatches of the TIMED frames only — the figure bench.py's HIP-event mean must agree with."""
     f = glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True)[0]
     df = pd.read_csv(f)
     df["Name"] = df["Name"].map(short)
     df["AverageUs"] = (df["AverageNs"] / 1e3).round(2)
     df["TotalMs"] = (df["TotalDurationNs"] / 1e6).round(3)
     cols = ["Name", "Calls", "TotalMs", "AverageUs", "Percentage", "MinNs", "MaxNs"]
+    note = ""
+    if total_steps:
+        t = pd.read_csv(glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0]).sort_values("Start_Timestamp")
+        t["Name"] = t["Kernel_Name"].map(short)
+        t["us"] = (t["End_Timestamp"] - t["Start_Timestamp"]) / 1e3
+        timed = {}
+        for name, g in t.groupby("Name"):
+            if len(g) % total_steps == 0 and len(g) >= total_steps:
+                per = len(g) // total_steps
+                timed[name] = round(float(g["us"].iloc[first_timed * per:(first_timed + n_timed) * per].mean()), 2)
+        df["TimedFramesUs"] = df["Name"].map(timed)
+        cols.insert(4, "TimedFramesUs")
+        note = (f"TimedFramesUs = mean over the dispatches of simulation frames [{first_timed}, {first_timed + n_timed}) "
+                f"(the timed region of `bench.py --steps {n_timed}`; {total_steps} frames per run); AverageUs covers all frames "
+                f"incl. the settle phase, where the lists are shorter.\n\n")
     with open(out, "w") as fh:
-        fh.write(f"# rocprofv3 --kernel-trace --stats summary ({os.path.basename(f)})\n\n")
+        fh.write(f"# rocprofv3 --kernel-trace --stats summary ({os.path.basename(f)})\n\n{note}")
         fh.write(df[cols].to_markdown(index=False))
         fh.write("\n")
     print(df[cols].to_string(index=False))
@@ -66,6 +83,6 @@ def pmc(dirs, out):
 
 if __name__ == "__main__":
     if sys.argv[1] == "kernel":
-        kernel(sys.argv[2], sys.argv[3])
+        kernel(sys.argv[2], sys.argv[3], *[int(v) for v in sys.argv[4:7]])
     else:
         pmc(sys.argv[2:-1], sys.argv[-1])
