@@ -285,8 +285,10 @@ def main():
             total_particles = n
             per_rank = max(1, n // world)
             rebalance = 8
-        cap_ghost = max(per_rank // 4, 1 << 15)  # wire records per neighbour: copies of one boundary column
-        cap_mig = max(per_rank // 16, 1 << 13)   # particles crossing a cut in one step
+        # records in the FIRST message of the two assembly rounds (what does not fit follows in a second, exactly
+        # sized exchange): about one boundary column of copies / an ordinary step's migrants
+        cap_ghost = max(per_rank // 8, 1 << 14)
+        cap_mig = max(per_rank // 64, 1 << 12)
         solver._chk(solver.L.pbf_reserve(solver.ctx, 3 * per_rank + 2 * cap_ghost), "pbf_reserve")  # head-room if the load drifts
         solver.upload(**mine)
         drv = slab.CSlabSolver(solver, dist, torch, rank, world, cuts, cap_mig, cap_ghost,

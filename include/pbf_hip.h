@@ -208,9 +208,11 @@ int pbf_slab_column_histogram(pbf_ctx *ctx, uint32_t out[1024]);
  * wire capacities to the ctx; pbf_slab_step then runs ONE step including every exchange:
  *   predict -> [migrants] -> [ghost copies] -> sort -> diffuse -> K x { lambda -> [field] -> delta -> [field] }
  *   -> finalise                ([..] = one exchange round: 2 + 2K rounds per step)
- * The two assembly rounds carry their record counts in a header of a capacity-sized message (no count round trip);
- * the host reads those counts once per assembly round (2 small synchronising read-backs per step), the 2K field
- * rounds need none.  A record count beyond the capacity is an error (PBF_ERR_COMM), never silent loss. */
+ * The two assembly rounds carry their record counts in the header of a fixed-size first message {header | first
+ * cap_* records} (no count round trip); the host reads those counts once per assembly round (2 small synchronising
+ * read-backs per step), the 2K field rounds need none.  Only when a side holds more records than the first message
+ * takes (a re-cut hands whole columns over) a second, exactly sized exchange follows.  Running out of wire buffer
+ * (half the particle capacity per neighbour) is an error (PBF_ERR_COMM), never silent loss. */
 typedef struct pbf_comm pbf_comm;
 #define PBF_COMM_ID_BYTES 128
 typedef int (*pbf_exchange_fn)(void *user, const void *send_left, size_t send_left_bytes, const void *send_right,
@@ -225,7 +227,8 @@ uint64_t pbf_comm_rounds(const pbf_comm *comm);        /* exchange rounds so far
 /* in-place sum over all ranks of `count` uint32 in DEVICE memory (load balance: column histograms); RCCL
  * communicators only (a host-callback communicator returns PBF_ERR_COMM: its caller reduces on the host) */
 int pbf_comm_allreduce_u32(pbf_comm *comm, void *device_u32, size_t count, void *stream);
-/* cuts[nranks + 1]; cap_migrants / cap_ghosts = wire capacity in records per neighbour.  The ctx keeps the pointer
+/* cuts[nranks + 1]; cap_migrants / cap_ghosts = records per neighbour in the FIRST message of the two assembly rounds
+ * (size them for an ordinary step: a fraction of / one boundary column).  The ctx keeps the pointer
  * to comm (not owned).  Switches the ctx to the rank-local key frame (pbf_slab_configure). */
 int pbf_slab_attach(pbf_ctx *ctx, pbf_comm *comm, const uint32_t *cuts, uint32_t cap_migrants, uint32_t cap_ghosts);
 int pbf_slab_set_cuts(pbf_ctx *ctx, const uint32_t *cuts); /* load balance: new cuts (same on every rank) */

@@ -70,6 +70,8 @@ struct pbf_ctx {
   // slab decomposition (pbf_slab_*): bookkeeping of what was sent / received this step
   DevBuf slotOf, selCounts, selTotals, ghostSrcL, ghostSrcR, colHist;
   bool slabActive = false, realObstacles = false;
+  bool ghostsPending = false;  // pbf_slab_step leaves the copies in place (the next step's migration select drops them);
+                               // anything that looks at the particle arrays from outside drops them first (drop_ghosts)
   bool slabConfigured = false;  // pbf_slab_configure: rank-local x frame for the keys (compact table per rank)
   pbf_slab_cut slabCut{0, 0, 0, 0};
   uint32_t xoff = 0;
@@ -77,7 +79,8 @@ struct pbf_ctx {
   // pbf_slab_attach: the whole step incl. the exchanges runs inside the library (pbf_slab_step)
   pbf_comm *comm = nullptr;  // not owned
   std::vector<uint32_t> cuts;
-  uint32_t capMig = 0, capGhost = 0;
+  uint32_t capMig = 0, capGhost = 0;  // records in the FIRST message of an assembly round (the rest follows when needed)
+  uint32_t wireCap = 0;               // records the wire buffers hold per neighbour
   DevBuf wireSend[2], wireRecv[2];
   uint32_t *hostCounts = nullptr;  // pinned: read-back of the assembly rounds' counts
   size_t reserve = 0;        // pbf_reserve: capacity kept for migrants and ghost copies
@@ -693,12 +696,15 @@ int check(pbf_ctx *ctx, const pbf_params *p, bool needSorted) {
   return PBF_OK;
 }
 
+int drop_ghosts(pbf_ctx *ctx);  // (defined with the slab code)
+
 template <typename N>
 int upload_impl(pbf_ctx *ctx, size_t n, const uint64_t *id, const uint8_t *type, const N *mass, const N *pos,
                 const N *vel, const N *colour) {
   if (int rc = ensure_particles(ctx, n)) return rc;
   if (int rc = drop_histogram(ctx)) return rc;
   ctx->cur = 0, ctx->pcur = 0, ctx->sorted = false;
+  ctx->ghostsPending = false, ctx->slabActive = false;
   ctx->n = n;
   ctx->hasObstacles = false;
   if (n == 0) return PBF_OK;
@@ -721,6 +727,7 @@ int upload_impl(pbf_ctx *ctx, size_t n, const uint64_t *id, const uint8_t *type,
 
 template <typename N>
 int download_impl(pbf_ctx *ctx, uint64_t *id, uint8_t *type, N *mass, N *pos, N *vel, N *colour) {
+  if (int rc = drop_ghosts(ctx)) return rc;
   const size_t n = ctx->n;
   if (n == 0) return PBF_OK;
   const int s = ctx->cur;
@@ -889,7 +896,7 @@ int pbf_download(pbf_ctx *ctx, uint64_t *id, uint8_t *type, void *mass, void *po
   return download_impl<float>(ctx, id, type, (float *)mass, (float *)pos, (float *)vel, (float *)colour);
 }
 
-size_t pbf_count(const pbf_ctx *ctx) { return ctx ? ctx->n : 0; }
+size_t pbf_count(const pbf_ctx *ctx) { return ctx ? (ctx->ghostsPending ? ctx->nOwned : ctx->n) : 0; }
 
 namespace {
 // Page-lock the caller's AoS buffer once and keep the registration while the same buffer comes back every frame
@@ -917,6 +924,7 @@ int pbf_upload_aos(pbf_ctx *ctx, size_t n, const void *particles, const pbf_aos_
   if (int rc = ensure_particles(ctx, n)) return rc;
   if (int rc = drop_histogram(ctx)) return rc;
   ctx->cur = 0, ctx->pcur = 0, ctx->sorted = false, ctx->n = n;
+  ctx->ghostsPending = false, ctx->slabActive = false;
   ctx->hasObstacles = false;
   if (n == 0) return PBF_OK;
   const uint8_t *src = static_cast<const uint8_t *>(particles);
@@ -947,6 +955,7 @@ int pbf_download_aos(pbf_ctx *ctx, void *particles, const pbf_aos_layout *l) {
   if (!ctx) return PBF_ERR_INVALID;
   if (!l || (ctx->n && !particles)) return fail(ctx, PBF_ERR_INVALID, "NULL argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (int rc = drop_ghosts(ctx)) return rc;
   const size_t n = ctx->n;
   if (n == 0) return PBF_OK;
   const size_t before = ctx->staging.cap;
@@ -976,10 +985,12 @@ int pbf_download_aos(pbf_ctx *ctx, void *particles, const pbf_aos_layout *l) {
 
 int pbf_step(pbf_ctx *ctx, const pbf_params *p) {
   if (int rc = check(ctx, p, false)) return rc;
+  if (int rc = drop_ghosts(ctx)) return rc;
   return DISPATCH(ctx, step_impl, ctx, p);
 }
 int pbf_steps(pbf_ctx *ctx, const pbf_params *p, uint32_t count) {
   if (int rc = check(ctx, p, false)) return rc;
+  if (int rc = drop_ghosts(ctx)) return rc;
   for (uint32_t i = 0; i < count; ++i)
     if (int rc = DISPATCH(ctx, step_impl, ctx, p)) return rc;
   return PBF_OK;
@@ -1021,6 +1032,8 @@ int pbf_stage_finalise(pbf_ctx *ctx, const pbf_params *p) {
 int pbf_read_buffer(pbf_ctx *ctx, int which, void *host, size_t bytes) {
   if (!ctx || !host) return PBF_ERR_INVALID;
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (which != PBF_BUF_NBR_COUNT)  // (the list lengths are indexed like the arrays the last build saw)
+    if (int rc = drop_ghosts(ctx)) return rc;
   const void *src = nullptr;
   size_t avail = 0;
   const size_t v = ctx->fp64 ? sizeof(double4) : sizeof(float4);
@@ -1031,7 +1044,7 @@ int pbf_read_buffer(pbf_ctx *ctx, int which, void *host, size_t bytes) {
       src = ctx->table.p, avail = size_t(ctx->tableN) * 4;
       break;
     case PBF_BUF_PSTAR: src = ctx->pstar[ctx->pcur].p, avail = ctx->n * v; break;
-    case PBF_BUF_NBR_COUNT: src = ctx->nbrCount.p, avail = ctx->n * 4; break;
+    case PBF_BUF_NBR_COUNT: src = ctx->nbrCount.p, avail = (ctx->ghostsPending ? ctx->nOwned : ctx->n) * 4; break;
     default: return fail(ctx, PBF_ERR_INVALID, "unknown buffer");
   }
   if (bytes > avail) return fail(ctx, PBF_ERR_INVALID, "read beyond buffer");
@@ -1218,6 +1231,12 @@ int slab_check(pbf_ctx *ctx) {
   return PBF_OK;
 }
 
+int drop_ghosts(pbf_ctx *ctx) {
+  if (!ctx->ghostsPending) return PBF_OK;
+  ctx->ghostsPending = false;
+  return DISPATCH(ctx, slab_finish, ctx, /*knownOwned=*/true);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1293,6 +1312,7 @@ int pbf_slab_unpack(pbf_ctx *ctx, const void *recv_left, const void *recv_right)
 }
 int pbf_slab_finish(pbf_ctx *ctx) {
   if (int rc = slab_check(ctx)) return rc;
+  ctx->ghostsPending = false;
   return DISPATCH(ctx, slab_finish, ctx);
 }
 size_t pbf_owned_count(const pbf_ctx *ctx) { return ctx ? (ctx->slabActive ? ctx->nOwned : ctx->n) : 0; }
@@ -1336,32 +1356,35 @@ int apply_cuts(pbf_ctx *ctx) {
   return pbf_slab_configure(ctx, &c, r > 0 ? ctx->cuts[r - 1] : 0, r + 1 < n ? ctx->cuts[r + 1] : 0);
 }
 
-int exchange(pbf_ctx *ctx, size_t nSL, size_t nSR, size_t nRL, size_t nRR) {
-  const int rc = comm_exchange(ctx->comm, ctx->stream, ctx->wireSend[0].p, nSL, ctx->wireSend[1].p, nSR, ctx->wireRecv[0].p,
-                               nRL, ctx->wireRecv[1].p, nRR);
+int exchange(pbf_ctx *ctx, size_t nSL, size_t nSR, size_t nRL, size_t nRR, size_t offset = 0) {
+  const int rc = comm_exchange(ctx->comm, ctx->stream, ctx->wireSend[0].as<uint8_t>() + offset, nSL,
+                               ctx->wireSend[1].as<uint8_t>() + offset, nSR, ctx->wireRecv[0].as<uint8_t>() + offset, nRL,
+                               ctx->wireRecv[1].as<uint8_t>() + offset, nRR);
   if (rc) ctx->err = "slab exchange: " + ctx->comm->err;
   return rc;
 }
 
-// One assembly round: select + pack (MODE), counts into the message headers, ONE exchange of capacity-sized
-// messages, then one small read-back {own totals[3], header from the left, header from the right}.
+// One assembly round: select + pack (MODE), counts into the message headers, ONE exchange of a fixed-size first
+// message {header | first `chunk` records}, then one small read-back {own totals[3], header from the left, header
+// from the right}.  Only when a side holds more than `chunk` records (a re-cut hands whole columns over; the start
+// lattice's blow-up) a second exchange moves the remainder — with exact sizes, which both ends of a link know by then.
 template <typename N, int MODE>
-int assembly_round(pbf_ctx *ctx, uint32_t cap, size_t recBytes, int idxL, int idxR, uint32_t own[3], uint32_t got[2]) {
+int assembly_round(pbf_ctx *ctx, uint32_t chunk, size_t recBytes, int idxL, int idxR, uint32_t own[3], uint32_t got[2]) {
   const pbf_slab_cut cut = cut_of(ctx);
   uint8_t *sL = ctx->wireSend[0].as<uint8_t>(), *sR = ctx->wireSend[1].as<uint8_t>();
   uint8_t *rL = ctx->wireRecv[0].as<uint8_t>(), *rR = ctx->wireRecv[1].as<uint8_t>();
   uint32_t t[3];
   if (int rc = ensure(ctx, ctx->selTotals, 16)) return rc;
   if (ctx->n == 0) HIPCHK(ctx, hipMemsetAsync(ctx->selTotals.p, 0, 16, ctx->stream));
-  if (int rc = run_select<N, MODE>(ctx, &cut, sL + WIRE_HDR, sR + WIRE_HDR, cap, t, false)) return rc;
+  if (int rc = run_select<N, MODE>(ctx, &cut, sL + WIRE_HDR, sR + WIRE_HDR, ctx->wireCap, t, false)) return rc;
   hipLaunchKernelGGL(k_wire_headers, dim3(1), dim3(64), 0, ctx->stream, ctx->selTotals.as<const uint32_t>(), idxL, idxR,
                      reinterpret_cast<uint32_t *>(sL), reinterpret_cast<uint32_t *>(sR));
   LAUNCH_CHECK(ctx);
-  const size_t bytes = WIRE_HDR + size_t(cap) * recBytes;
+  const size_t first = WIRE_HDR + size_t(chunk) * recBytes;
   // a rank without that neighbour neither sends nor receives on that side: its header reads 0
   HIPCHK(ctx, hipMemsetAsync(rL, 0, WIRE_HDR, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(rR, 0, WIRE_HDR, ctx->stream));
-  if (int rc = exchange(ctx, bytes, bytes, bytes, bytes)) return rc;
+  if (int rc = exchange(ctx, first, first, first, first)) return rc;
   uint32_t *h = ctx->hostCounts;
   HIPCHK(ctx, hipMemcpyAsync(h, ctx->selTotals.p, 12, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(h + 4, rL, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1369,9 +1392,13 @@ int assembly_round(pbf_ctx *ctx, uint32_t cap, size_t recBytes, int idxL, int id
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the one read-back of this round: counts size the launches below
   own[0] = h[0], own[1] = h[1], own[2] = h[2];
   got[0] = h[4], got[1] = h[5];
-  if (own[idxL] > cap || own[idxR] > cap || got[0] > cap || got[1] > cap)
-    return fail(ctx, PBF_ERR_COMM, "slab wire capacity exceeded (" + std::to_string(std::max(std::max(own[idxL], own[idxR]), std::max(got[0], got[1]))) +
-                                       " records > " + std::to_string(cap) + "): attach with larger capacities");
+  const uint32_t most = std::max(std::max(own[idxL], own[idxR]), std::max(got[0], got[1]));
+  if (most > ctx->wireCap)
+    return fail(ctx, PBF_ERR_COMM, "slab wire buffers too small (" + std::to_string(most) + " records > " +
+                                       std::to_string(ctx->wireCap) + "): pbf_reserve a larger particle capacity before attaching");
+  auto rest = [&](uint32_t count) { return count > chunk ? size_t(count - chunk) * recBytes : size_t(0); };
+  if (most > chunk)  // (both ends of a link see the same count for it: sizes agree, empty links are skipped)
+    if (int rc = exchange(ctx, rest(own[idxL]), rest(own[idxR]), rest(got[0]), rest(got[1]), first)) return rc;
   return PBF_OK;
 }
 
@@ -1405,7 +1432,10 @@ template <typename N> int slab_step_impl(pbf_ctx *ctx, const pbf_params *p) {
     if (int rc = refresh()) return rc;
   }
   if (int rc = stage_finalise<N>(ctx, p)) return rc;
-  return slab_finish<N>(ctx, /*knownOwned=*/true);
+  // The copies stay where they are: the next step's migration select drops them on its way (one whole-array
+  // compaction per step saved); whoever looks at the arrays from outside calls drop_ghosts() first.
+  ctx->ghostsPending = true;
+  return PBF_OK;
 }
 
 }  // namespace
@@ -1509,7 +1539,10 @@ int pbf_slab_attach(pbf_ctx *ctx, pbf_comm *comm, const uint32_t *cuts, uint32_t
   ctx->capMig = cap_migrants, ctx->capGhost = cap_ghosts;
   const size_t mig = ctx->fp64 ? sizeof(MigrantRec<double>) : sizeof(MigrantRec<float>);
   const size_t gho = ctx->fp64 ? sizeof(GhostRec<double>) : sizeof(GhostRec<float>);
-  const size_t bytes = WIRE_HDR + std::max(size_t(cap_migrants) * mig, size_t(cap_ghosts) * gho);
+  // the buffers hold far more than the first message: half the particle capacity per neighbour (whole columns change
+  // hands after a re-cut) — a few hundred MB at most, nothing against 288 GB of HBM
+  ctx->wireCap = uint32_t(std::max<size_t>(std::max<size_t>(ctx->cap, ctx->reserve) / 2, 4 * size_t(std::max(cap_migrants, cap_ghosts))));
+  const size_t bytes = WIRE_HDR + size_t(ctx->wireCap) * std::max(mig, gho);
   for (int k = 0; k < 2; ++k) {
     if (int rc = ensure(ctx, ctx->wireSend[k], bytes)) return rc;
     if (int rc = ensure(ctx, ctx->wireRecv[k], bytes)) return rc;
@@ -1601,6 +1634,7 @@ extern "C" {
 
 int pbf_surface(pbf_ctx *ctx, const pbf_params *params, const pbf_mc_params *mc, uint64_t *n_triangles) {
   if (int rc = check(ctx, params, true)) return rc;
+  if (ctx->ghostsPending) return fail(ctx, PBF_ERR_INVALID, "pbf_surface is not available in slab mode yet");
   if (!mc || !n_triangles) return fail(ctx, PBF_ERR_INVALID, "NULL argument");
   if (!(mc->resolution > 0)) return fail(ctx, PBF_ERR_INVALID, "resolution must be > 0");
   return DISPATCH(ctx, surface_impl, ctx, params, mc, n_triangles);

@@ -274,9 +274,10 @@ public:
       part[g].push_back(xs[i]);
     }
     const size_t per = std::max<size_t>(xs.size() / n, 1);
-    const uint32_t capGhost = uint32_t(std::max<size_t>(per / 4, 1u << 15)), capMig = uint32_t(std::max<size_t>(per / 16, 1u << 13));
+    // records in the first message of the two assembly rounds (the remainder follows when needed)
+    const uint32_t capGhost = uint32_t(std::max<size_t>(per / 8, 1u << 14)), capMig = uint32_t(std::max<size_t>(per / 64, 1u << 12));
     for (int g = 0; g < n; ++g) {
-      if (!attached_) checkOn(g, pbf_reserve(slabs_[g], 3 * per + 2 * capGhost), "pbf_reserve");
+      if (!attached_) checkOn(g, pbf_reserve(slabs_[g], 3 * per + (1u << 16)), "pbf_reserve");
       checkOn(g, pbf_upload_aos(slabs_[g], part[g].size(), part[g].data(), &l), "pbf_upload_aos");
       if (!attached_) checkOn(g, pbf_slab_attach(slabs_[g], comms_[g], cuts_.data(), capMig, capGhost), "pbf_slab_attach");
     }

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--cuts", default="even")
     ap.add_argument("--fp64", action="store_true")
     ap.add_argument("--rebalance", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0, help="records in the first message of an assembly round (hipc)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -63,7 +64,7 @@ def main():
         get = s.download
         stage = True
     if a.engine == "hipc":
-        drv = slab.CSlabSolver(s, dist, torch, rank, world, cuts, cap, cap, transport="gloo-host",
+        drv = slab.CSlabSolver(s, dist, torch, rank, world, cuts, a.chunk or cap, a.chunk or cap, transport="gloo-host",
                                rebalance_every=a.rebalance)
         drv.steps(p, a.steps)
         stats = dict(migrated=-1, ghosts=-1, exchanges=drv.rounds, recuts=drv.stats["recuts"])

@@ -40,6 +40,18 @@ def test_hip_slabs_bit_exact_vs_oracle_slabs(pkg, tmp_path, engine, world, cuts)
     assert d.max() <= 2e-2 and d.mean() <= 1e-4, (d.max(), d.mean())
 
 
+def test_hip_slabs_small_first_message(pkg, tmp_path):
+    """First assembly message of only 16 records: the ghost copies (hundreds per boundary column) do not fit, so every
+    step takes the second, exactly sized exchange as well — same particles, same bits as the CPU twin."""
+    args = ("--scene", "cubes2048", "--steps", "4", "--cuts", "x:210,700")
+    hip = launch(3, str(tmp_path / "hip"), "--engine", "hipc", "--chunk", "16", *args)
+    ora = launch(3, str(tmp_path / "ora"), "--engine", "oracle", *args)
+    for r in range(3):
+        for k in ("id", "pos", "vel", "colour", "type"):
+            assert np.array_equal(hip[r][k], ora[r][k]), (r, k)
+    assert int(hip[1]["exchanges"]) > 4 * (2 + 2 * 4)   # the remainder rounds happened
+
+
 def test_hip_slabs_fp64_bit_exact(pkg, tmp_path):
     args = ("--scene", "cubes2048", "--steps", "4", "--cuts", "x:210", "--fp64")
     hip = launch(2, str(tmp_path / "hip"), "--engine", "hipc", *args)
