@@ -277,14 +277,14 @@ def main():
             rebalance = 0
         else:
             # BASELINE.json configs[3]: ONE column (4 M nominal at N = 8) cut into `world` x-slabs holding equal
-            # particle counts (slab.balanced_cuts), re-cut every 8 steps as the column collapses (slab.recut).
+            # particle counts (slab.balanced_cuts), re-cut every 4 steps as the column collapses (slab.recut).
             cuts = slab.balanced_cuts(world, scene["pos"][:, 0], side)
             col = slab.columns_of(scene["pos"][:, 0])
             sel = (col >= cuts[rank]) & (col < cuts[rank + 1])
             mine = {k: v[sel] for k, v in scene.items()}
             total_particles = n
             per_rank = max(1, n // world)
-            rebalance = 8
+            rebalance = int(os.environ.get("PBF_BENCH_REBALANCE", "4"))
         # records in the FIRST message of the two assembly rounds (what does not fit follows in a second, exactly
         # sized exchange): about one boundary column of copies / an ordinary step's migrants
         cap_ghost = max(per_rank // 8, 1 << 14)
@@ -412,7 +412,7 @@ def main():
                                        ("ncclSend/ncclRecv over xGMI" if backend == "nccl" else "host-callback transport (gloo rehearsal)") +
                                        f", {drv.rounds // max(1, drv.frame)} exchange rounds per step; " +
                                        (f"{world} columns side by side, odd ones mirrored" if scaling == "weak" else
-                                        "ONE column, particle-balanced cuts, re-cut every 8 steps") +
+                                        f"ONE column, particle-balanced cuts, re-cut every {drv.rebalance_every} steps ({drv.stats['recuts']} re-cuts so far)") +
                                        f"; max rank load {imbalance:.2f}x mean")},
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stopwatch_entry": dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
