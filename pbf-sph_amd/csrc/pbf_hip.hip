@@ -108,6 +108,13 @@ struct pbf_ctx {
   int coop = 0;              // option "coop": 0 = one lane per particle (bit-exact), 2 / 4 / 8 = lanes sharing a particle's
                              // list with a wave-shuffle reduction (k_gather_from_lists_coop; rounding-level differences)
   bool cellDiffuse = true;   // option "cell_diffuse": one walk per occupied cell instead of one per particle
+  // option "overlap_diffuse" (default on): inside pbf_step the colour diffusion — memory-latency bound, 85 % of its wave
+  // time parked — runs on a side stream beside the VALU-bound solver iterations (nothing else touches colours)
+  bool overlapDiffuse = true;
+  hipStream_t sideStream = nullptr;
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
+  bool diffusePending = false;
+  DevBuf diffSum, diffCnt;   // the overlapped diffusion's own per-cell scratch
   bool fuseDiffuse = false;  // option "fuse_diffuse": pbf_step folds the diffuse walk into the first lambda launch
                              // (bit-identical; measured 2 % SLOWER at 1 M — the colour loads stall the filter loop — so off)
   bool fuseDiffuseNow = false;
@@ -528,29 +535,61 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
   }
 }
 
-template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p) {
+// The overlapped diffusion must be done before anything rewrites what it reads (colours, types, keys, table, brick
+// list: the next sort) or reads what it writes (colours: download, surface).  Stream-side wait, no host sync.
+int join_diffuse(pbf_ctx *ctx) {
+  if (!ctx->diffusePending) return PBF_OK;
+  ctx->diffusePending = false;
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
+  return PBF_OK;
+}
+
+template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p, bool overlap = false) {
   StepConsts<N> c;
   if (int rc = make_consts<N>(ctx, p, c)) return rc;
-  StageTimer t(ctx, ST_DIFFUSE);
   const int s = ctx->cur, d = 1 - s;  // col4[d] is free after the sort
   typename DiffuseOp<N>::Args args{ctx->col4[s].as<const vec4<N>>(), ctx->col4[d].as<vec4<N>>(),
                                    ctx->type[s].as<const uint8_t>()};
+  const bool timed = (ctx->desc.flags & PBF_FLAG_STAGE_TIMING) != 0 && ((ctx->timingMask >> ST_DIFFUSE) & 1u) != 0;
+  overlap = overlap && ctx->overlapDiffuse && ctx->cellDiffuse && !(ctx->desc.flags & PBF_FLAG_NO_LDS) && !timed;
+  StageTimer t(ctx, ST_DIFFUSE);
   if (ctx->cellDiffuse && !(ctx->desc.flags & PBF_FLAG_NO_LDS)) {
-    // sums per cell, parked in buffers that are idle here: the Jacobi partner of pStar and the list lengths
+    // sums per cell, parked in buffers that are idle here (the Jacobi partner of pStar and the list lengths) — or, when
+    // the stage runs beside the solver iterations, in scratch of its own
     vec4<N> *cellSum = ctx->pstar[other_pstar(ctx)].as<vec4<N>>();
     uint32_t *cellCnt = ctx->nbrCount.as<uint32_t>();
-    const uint32_t *key = ctx->key[s].as<const uint32_t>(), *table = ctx->table.as<const uint32_t>();
-    static_assert(kBrickZ == 4, "the sort stage's brick list is the 4 x 4 x 4 one");
+    hipStream_t st = ctx->stream;
     const uint32_t cap = sizeof(vec4<N>) == 16 ? 3072u : 1536u;  // 48 KiB of colours: 216 cells x 14 (7) particles
     const size_t lds = Brick<4>::HDR + size_t(cap) * sizeof(vec4<N>);
-    const uint32_t perCU = uint32_t((160 * 1024) / (lds + 1024));
+    uint32_t perCU = uint32_t((160 * 1024) / (lds + 1024));
+    if (overlap) {
+      if (int rc = ensure(ctx, ctx->diffSum, ctx->cap * sizeof(vec4<N>))) return rc;
+      if (int rc = ensure(ctx, ctx->diffCnt, ctx->cap * 4)) return rc;
+      if (!ctx->sideStream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->sideStream, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming));
+      }
+      cellSum = ctx->diffSum.as<vec4<N>>(), cellCnt = ctx->diffCnt.as<uint32_t>();
+      st = ctx->sideStream;
+      perCU = 1;  // one 48-KiB workgroup per CU: the list build's staging lists (24 KiB per workgroup) keep their room
+      HIPCHK(ctx, hipEventRecord(ctx->evFork, ctx->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(st, ctx->evFork, 0));
+    }
+    const uint32_t *key = ctx->key[s].as<const uint32_t>(), *table = ctx->table.as<const uint32_t>();
+    static_assert(kBrickZ == 4, "the sort stage's brick list is the 4 x 4 x 4 one");
     hipLaunchKernelGGL((k_diffuse_bricks<N>), dim3(uint32_t(ctx->numCUs) * perCU), dim3(DIFFUSE_BRICK_THREADS), lds,
-                       ctx->stream, c, args.colIn, args.type, table, ctx->bricks.as<const uint32_t>(),
+                       st, c, args.colIn, args.type, table, ctx->bricks.as<const uint32_t>(),
                        ctx->brickCtl.as<const uint32_t>(), cellSum, cellCnt, cap);
-    hipLaunchKernelGGL((k_diffuse_apply<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table,
+    hipLaunchKernelGGL((k_diffuse_apply<N>), grid_for(ctx->n), dim3(BLOCK), 0, st, c, args, key, table,
                        cellSum, cellCnt);
     LAUNCH_CHECK(ctx);
-    ctx->nbrValid = false;
+    if (overlap) {
+      HIPCHK(ctx, hipEventRecord(ctx->evJoin, st));
+      ctx->diffusePending = true;
+    } else {
+      ctx->nbrValid = false;
+    }
   } else if (int rc = launch_gather<N, DiffuseOp<N>>(ctx, c, args)) {
     return rc;
   }
@@ -675,14 +714,15 @@ template <typename N> int step_impl(pbf_ctx *ctx, const pbf_params *p) {
   const bool fuse = ctx->fuseDiffuse && p->iteration > 0 && ctx->gatherKind == 1 && ctx->reuseLists &&
                     !(ctx->desc.flags & PBF_FLAG_NO_LDS);
   if (!fuse) {
-    if (int rc = stage_diffuse<N>(ctx, p)) return rc;
+    if (int rc = stage_diffuse<N>(ctx, p, /*overlap=*/p->iteration > 0)) return rc;
   }
   ctx->fuseDiffuseNow = fuse;
   for (uint64_t it = 0; it < p->iteration; ++it) {
     if (int rc = stage_lambda<N>(ctx, p)) return rc;
     if (int rc = stage_delta<N>(ctx, p)) return rc;
   }
-  return stage_finalise<N>(ctx, p);
+  if (int rc = stage_finalise<N>(ctx, p)) return rc;
+  return join_diffuse(ctx);  // the step is complete on ctx->stream only once the colours are
 }
 
 int check(pbf_ctx *ctx, const pbf_params *p, bool needSorted) {
@@ -771,6 +811,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   else if (n == "reuse_lists") ctx->reuseLists = value != 0;
   else if (n == "fuse_diffuse") ctx->fuseDiffuse = value != 0;
   else if (n == "cell_diffuse") ctx->cellDiffuse = value != 0;
+  else if (n == "overlap_diffuse") ctx->overlapDiffuse = value != 0;
   else if (n == "coop") {
     if (value != 0 && value != 2 && value != 4 && value != 8) return fail(ctx, PBF_ERR_INVALID, "coop must be 0, 2, 4 or 8");
     ctx->coop = int(value);
@@ -827,6 +868,7 @@ int pbf_create(const pbf_desc *desc, pbf_ctx **out) {
   if (const char *e = std::getenv("PBF_REUSE_LISTS")) ctx->reuseLists = std::atoi(e) != 0;
   if (const char *e = std::getenv("PBF_SPLIT_BUILD")) ctx->splitBuild = std::atoi(e);
   if (const char *e = std::getenv("PBF_LIST_MAX")) ctx->listMax = uint32_t(std::atoi(e));
+  if (const char *e = std::getenv("PBF_OVERLAP_DIFFUSE")) ctx->overlapDiffuse = std::atoi(e) != 0;
   if (const char *e = std::getenv("PBF_COOP")) {
     const int v = std::atoi(e);
     if (v == 0 || v == 2 || v == 4 || v == 8) ctx->coop = v;
@@ -864,9 +906,12 @@ void pbf_destroy(pbf_ctx *ctx) {
                    &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2], &ctx->count, &ctx->table,   &ctx->blockSums,
                    &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl, &ctx->bigCells,
                    &ctx->latticePN, &ctx->latticeC, &ctx->mcCounts, &ctx->mcOffsets, &ctx->mcSums, &ctx->meshV, &ctx->meshN,
-                   &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR, &ctx->colHist, &ctx->wireSend[0], &ctx->wireSend[1], &ctx->wireRecv[0], &ctx->wireRecv[1]};
+                   &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR, &ctx->colHist, &ctx->wireSend[0], &ctx->wireSend[1], &ctx->wireRecv[0], &ctx->wireRecv[1], &ctx->diffSum, &ctx->diffCnt};
   for (DevBuf *b : all)
     if (b->p) (void)hipFree(b->p);
+  if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
+  if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
+  if (ctx->sideStream) (void)hipStreamDestroy(ctx->sideStream);
   if (ctx->hostCounts) (void)hipHostFree(ctx->hostCounts);
   if (ctx->regPtr) (void)hipHostUnregister(ctx->regPtr);
   if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
