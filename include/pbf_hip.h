@@ -136,6 +136,11 @@ int pbf_read_buffer(pbf_ctx *ctx, int which, void *host, size_t bytes);
 size_t pbf_table_size(const pbf_ctx *ctx);                /* Morton(extent), sph.hpp:240 */
 int pbf_grid_extent(const pbf_ctx *ctx, uint64_t extent[3], double min_extent[3]); /* ompsph.hpp:132-135 */
 
+/* Device self-test of the range-trimmed IEEE sqrt / divide the precise pair terms use (csrc/pbf_kernels.hpp
+ * sqrt_ranged / div_ranged) against the compiler's full IEEE forms: mismatches[0] over EVERY fp32 value >= 2^-96,
+ * mismatches[1] over (h - r)^2 / r for every fp32 r in [1e-8, h], four h.  Both must be 0. */
+int pbf_selftest_math(pbf_ctx *ctx, uint64_t mismatches[2]);
+
 /* Mean milliseconds per call of each stage since the last pbf_reset_stage_times (needs
  * PBF_FLAG_STAGE_TIMING).  names[i] points at static strings that follow the reference's Stopwatch
  * entries (ompsph.hpp:130,157,161,188,209,252); an entry named "stage/part" is a sub-interval of "stage"

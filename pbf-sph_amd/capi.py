@@ -120,6 +120,7 @@ _SIGS = {
     "pbf_stage_finalise": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "pbf_read_buffer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "pbf_table_size": (C.c_size_t, [C.c_void_p]),
+    "pbf_selftest_math": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pbf_grid_extent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pbf_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                   C.c_int]),

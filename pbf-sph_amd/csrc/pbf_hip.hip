@@ -1099,6 +1099,21 @@ int pbf_read_buffer(pbf_ctx *ctx, int which, void *host, size_t bytes) {
   return PBF_OK;
 }
 
+int pbf_selftest_math(pbf_ctx *ctx, uint64_t mismatches[2]) {
+  if (!ctx || !mismatches) return PBF_ERR_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (int rc = ensure(ctx, ctx->selTotals, 16)) return rc;
+  HIPCHK(ctx, hipMemsetAsync(ctx->selTotals.p, 0, 16, ctx->stream));
+  hipLaunchKernelGGL(k_selftest_math, dim3(uint32_t(ctx->numCUs) * 8), dim3(BLOCK), 0, ctx->stream,
+                     ctx->selTotals.as<unsigned long long>());
+  LAUNCH_CHECK(ctx);
+  unsigned long long h[2] = {0, 0};
+  HIPCHK(ctx, hipMemcpyAsync(h, ctx->selTotals.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  mismatches[0] = h[0], mismatches[1] = h[1];
+  return PBF_OK;
+}
+
 size_t pbf_table_size(const pbf_ctx *ctx) { return ctx ? ctx->tableN : 0; }
 int pbf_grid_extent(const pbf_ctx *ctx, uint64_t extent[3], double min_extent[3]) {
   if (!ctx) return PBF_ERR_INVALID;

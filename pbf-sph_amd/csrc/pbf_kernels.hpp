@@ -366,6 +366,33 @@ template <typename N, bool FAST> struct PairGeom {
 __device__ inline float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ inline double fast_rsq(double x) { return 1.0 / sqrt(x); }  // fp64 keeps the IEEE forms
 
+// Correctly rounded sqrt and divide for the PRECISE pair terms, trimmed to the operand range they see (the readers
+// are VALU-issue bound: profiles/r02_pmc_sq_baseline.md).  hipcc's IEEE sqrtf is v_sqrt_f32 + a +-1 ulp fix-up wrapped
+// in a 2^32 rescale for inputs below 2^-96 and a class test: 16 VALU; here the same v_sqrt_f32 and the same fix-up
+// without the wrapper: 9.  For d2 >= 2^-96 the result is the IEEE one bit for bit (k_selftest_math sweeps every fp32
+// value); below — r < 3.6e-15, far under EPSILON — any small r gives the same pair terms: the spiky branch is off,
+// and h^2 - r^2 rounds to h^2.  Likewise hipcc's divide = v_div_scale x 2 + v_rcp + Newton + v_div_fmas +
+// v_div_fixup (11 VALU); with 1e-8 <= r <= h and 0 <= (h - r)^2 <= h^2 nothing needs scaling or fixing and the same
+// Newton steps alone (8 VALU) give the same bits; outside that range the quotient is never used (selected away).
+__device__ inline float sqrt_ranged(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+  const float em = fmaf(-sm, s, x), ep = fmaf(-sp, s, x);
+  float r = em <= 0.f ? sm : s;
+  r = ep > 0.f ? sp : r;
+  return r;
+}
+__device__ inline double sqrt_ranged(double x) { return sqrt(x); }
+__device__ inline float div_ranged(float a, float b) {
+  float y = __builtin_amdgcn_rcpf(b);
+  y = fmaf(fmaf(-b, y, 1.0f), y, y);
+  float q = a * y;
+  q = fmaf(fmaf(-b, q, a), y, q);
+  q = fmaf(fmaf(-b, q, a), y, q);
+  return q;
+}
+__device__ inline double div_ranged(double a, double b) { return a / b; }
+
 template <typename N, bool FAST>
 __device__ inline PairGeom<N, FAST> pair_geom(const vec4<N> &a, const vec4<N> &b, N h) {
   PairGeom<N, FAST> g;
@@ -381,11 +408,11 @@ __device__ inline PairGeom<N, FAST> pair_geom(const vec4<N> &a, const vec4<N> &b
     g.hr2_over_r = (hr * hr) * rinv;
   } else {
     const N d2 = bx * bx + by * by + bz * bz;
-    g.r = sqrt(d2);
+    g.r = sqrt_ranged(d2);
     g.inH = g.r <= h;
     g.inSpiky = g.inH && g.r >= N(EPSILON);
     const N hr = h - g.r;
-    g.hr2_over_r = (hr * hr) / g.r;
+    g.hr2_over_r = div_ranged(hr * hr, g.r);  // (only used where inSpiky)
   }
   return g;
 }
@@ -1561,6 +1588,30 @@ __global__ __launch_bounds__(BLOCK) void k_pack_aos(uint32_t n, uint8_t *__restr
   pos[0] = P.x, pos[1] = P.y, pos[2] = P.z;
   vel[0] = V.x, vel[1] = V.y, vel[2] = V.z;
   col[0] = C.x, col[1] = C.y, col[2] = C.z, col[3] = C.w;
+}
+
+// Exhaustive check of the trimmed sqrt / divide against hipcc's IEEE forms (pbf_selftest_math): every fp32 bit
+// pattern x >= 2^-96 for the sqrt; for the divide (h - r)^2 / r over r = every fp32 value in [1e-8, 0.1] x four h.
+__global__ __launch_bounds__(BLOCK) void k_selftest_math(unsigned long long *__restrict__ bad) {
+  unsigned long long badSqrt = 0, badDiv = 0;
+  const float hs[4] = {0.1f, 0.05f, 0.2f, 0.0999999f};
+  for (uint64_t v = uint64_t(blockIdx.x) * BLOCK + threadIdx.x; v < (1ull << 32); v += uint64_t(gridDim.x) * BLOCK) {
+    const float x = __int_as_float(int(uint32_t(v)));
+    if (x >= 0x1p-96f && x <= 3.0e38f) {
+      const float a = sqrt_ranged(x), b = sqrtf(x);
+      badSqrt += __float_as_int(a) != __float_as_int(b);
+    }
+    if (x >= 1e-8f && x <= 0.2f) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (x <= hs[k]) {
+          const float hr = hs[k] - x, num = hr * hr;
+          badDiv += __float_as_int(div_ranged(num, x)) != __float_as_int(num / x);
+        }
+    }
+  }
+  if (badSqrt) atomicAdd(&bad[0], badSqrt);
+  if (badDiv) atomicAdd(&bad[1], badDiv);
 }
 
 }  // namespace pbf

@@ -595,3 +595,13 @@ def test_wave_cooperative_reader_within_tolerance(pkg, oracle, coop, fp64):
     assert not np.array_equal(g["pos"], w["pos"]) or fp64 or coop == 0  # (it really is another summation order)
     dv = np.abs(g["vel"].astype(np.float64) - w["vel"]).max()
     assert dv <= (1e-3 if not fp64 else 1e-9), dv
+
+
+def test_ranged_sqrt_and_divide_are_the_ieee_ones(pkg):
+    """The precise pair terms use a sqrt and a divide trimmed to their operand range (no denormal rescale, no
+    v_div_scale / v_div_fixup): swept on the device against the compiler's IEEE forms over every fp32 value
+    (sqrt, x >= 2^-96) and every fp32 r in [1e-8, h] for (h - r)^2 / r — not one mismatch allowed."""
+    s = pkg.Solver(h=0.1)
+    bad = np.zeros(2, np.uint64)
+    s._chk(s.L.pbf_selftest_math(s.ctx, bad.ctypes.data_as(C.c_void_p)), "pbf_selftest_math")
+    assert bad[0] == 0 and bad[1] == 0, bad
