@@ -1558,10 +1558,11 @@ struct AosLayout {
 
 template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_unpack_aos(uint32_t n, const uint8_t *__restrict__ aos, AosLayout l,
-                                                      ParticleArrays<N> dst) {
+                                                      ParticleArrays<N> dst, uint32_t *__restrict__ anyObstacle) {
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint8_t *p = aos + size_t(i) * l.stride;
+  if (p[l.off_type] == 1) *anyObstacle = 1u;  // (sph::Type::Obstacle; found here instead of by a strided host scan)
   const N *pos = reinterpret_cast<const N *>(p + l.off_pos);
   const N *vel = reinterpret_cast<const N *>(p + l.off_vel);
   const N *col = reinterpret_cast<const N *>(p + l.off_colour);
