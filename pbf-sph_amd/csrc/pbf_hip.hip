@@ -105,6 +105,8 @@ struct pbf_ctx {
   // otherwise the build is a launch of its own followed by a list-driven lambda: 1 = k_gather_lists build-only,
   // 2 / 3 = k_build_lists 4- / 8-way on fp pStar, 4 / 5 = k_build_lists_q (quantised pairs) 2 / 4 loads per trip
   int splitBuild = 5;
+  int pipeline = -1;         // option "pipeline": software-pipelined list readers (bit-identical either way); -1 = auto:
+                             // fp64 only (measured at 1 M: fp64 -1.3 %, fp32 +3 % — fp32's readers are VALU-issue bound)
   int coop = 0;              // option "coop": 0 = one lane per particle (bit-exact), 2 / 4 / 8 = lanes sharing a particle's
                              // list with a wave-shuffle reduction (k_gather_from_lists_coop; rounding-level differences)
   bool cellDiffuse = true;   // option "cell_diffuse": one walk per occupied cell instead of one per particle
@@ -459,7 +461,10 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
           default: break;
         }
       }
-      hipLaunchKernelGGL((k_gather_from_lists<N, Op>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
+      if (ctx->pipeline < 0 ? sizeof(N) == 8 : ctx->pipeline != 0)
+        hipLaunchKernelGGL((k_gather_from_lists<N, Op, true>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
+      else
+        hipLaunchKernelGGL((k_gather_from_lists<N, Op, false>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
     };
     if (mode == GATHER_FROM_LISTS) {
       from_lists();
@@ -811,6 +816,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   else if (n == "reuse_lists") ctx->reuseLists = value != 0;
   else if (n == "fuse_diffuse") ctx->fuseDiffuse = value != 0;
   else if (n == "cell_diffuse") ctx->cellDiffuse = value != 0;
+  else if (n == "pipeline") ctx->pipeline = int(value);
   else if (n == "overlap_diffuse") ctx->overlapDiffuse = value != 0;
   else if (n == "coop") {
     if (value != 0 && value != 2 && value != 4 && value != 8) return fail(ctx, PBF_ERR_INVALID, "coop must be 0, 2, 4 or 8");
@@ -869,6 +875,7 @@ int pbf_create(const pbf_desc *desc, pbf_ctx **out) {
   if (const char *e = std::getenv("PBF_SPLIT_BUILD")) ctx->splitBuild = std::atoi(e);
   if (const char *e = std::getenv("PBF_LIST_MAX")) ctx->listMax = uint32_t(std::atoi(e));
   if (const char *e = std::getenv("PBF_OVERLAP_DIFFUSE")) ctx->overlapDiffuse = std::atoi(e) != 0;
+  if (const char *e = std::getenv("PBF_PIPELINE")) ctx->pipeline = std::atoi(e);
   if (const char *e = std::getenv("PBF_COOP")) {
     const int v = std::atoi(e);
     if (v == 0 || v == 2 || v == 4 || v == 8) ctx->coop = v;

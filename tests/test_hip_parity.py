@@ -177,6 +177,25 @@ def test_cell_diffuse_bit_exact(pkg, oracle, cell):
         assert_state_equal(s.download(), o.get_particles(), f"cell={cell} obstacles={obstacles}")
 
 
+@pytest.mark.parametrize("fp64", [False, True])
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_pipelined_readers_bit_exact(pkg, oracle, pipeline, fp64):
+    """Option pipeline: software-pipelined list-driven lambda / delta-p (default: fp64 only) — same candidates in the same
+    order, so identical bits either way, obstacles and overflowing rows (the pile) included."""
+    sc, side = get_scene(pkg, "dam8192", fp64)
+    sc = {k: v.copy() for k, v in sc.items()}
+    sc["type"][::13] = 1
+    sc["pos"][:300] = sc["pos"][0] + (np.arange(300)[:, None] % 7) * 0.5   # > 64 neighbours: rows overflow, particles walk
+    s, o = mk(pkg, oracle, sc, fp64)
+    s.set_option("pipeline", pipeline)
+    p, q = params_pair(pkg, oracle, side=side)
+    for frame in range(4):
+        s.step(p)
+        o.step(q)
+    assert (s.nbr_counts() == 0xFFFFFFFF).sum() > 0 or frame > 0
+    assert_state_equal(s.download(), o.get_particles())
+
+
 def test_no_lds_flag_bit_exact(pkg, oracle):
     """PBF_FLAG_NO_LDS: every gather stage (diffuse included) is the plain one-lane-per-particle walk."""
     sc, side = get_scene(pkg, "dam8192", False)
@@ -493,10 +512,10 @@ def test_stage_timing(pkg):
     assert all(ms > 0 for ms, _ in t.values())
 
 
-@pytest.mark.parametrize("nominal,fp64", [(262144, False), (1048576, False), (1048576, True)])
+@pytest.mark.parametrize("nominal,fp64", [(262144, False), (1048576, False), (1048576, True), (4194304, False)])
 def test_full_size_properties(pkg, nominal, fp64):
-    """BASELINE.json sizes (configs 2, 3 and 5: 256 K fp32, 1 M fp32, 1 M fp64): size-independent properties
-    instead of the oracle."""
+    """BASELINE.json sizes (configs 2, 3 and 5: 256 K fp32, 1 M fp32, 1 M fp64; and config 4's 4 M column on ONE GPU):
+    size-independent properties instead of the oracle."""
     sc, side = pkg.scene_dambreak(nominal, fp64)
     n = len(sc["id"])
     s = pkg.Solver(h=0.1, fp64=fp64)

@@ -96,6 +96,26 @@ def test_hip_slabs_rebalance_matches_cpu_twin(pkg, tmp_path):
     assert np.array_equal(merged(hip)["id"], np.sort(sc["id"]))
 
 
+def test_bench_strong_scaling_rehearsal(tmp_path):
+    """bench.py --gpus 4 as the driver would start it without torchrun (it launches its own ranks), strong scaling =
+    ONE column over 4 particle-balanced slabs with re-cuts; the 4 ranks share this GPU through the host-callback
+    transport (PBF_BENCH_BACKEND=gloo).  The JSON line is the only thing on stdout; nothing lost; load balanced."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "10", "--warmup", "5",
+                        "--settle-to", "60", "--particles", "262144", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, PBF_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["config"]["particles"] == 250000
+    assert "max rank load 1.0" in d["config"]["parallelism"] or "max rank load 1.1" in d["config"]["parallelism"]
+    assert "10 exchange rounds per step" in d["config"]["parallelism"] or "11 exchange rounds" in d["config"]["parallelism"]
+
+
 RCCL_SCRIPT = r"""
 import os, sys
 sys.path.insert(0, os.path.join({root!r}, "tests"))
