@@ -857,6 +857,85 @@ void pbf_oracle_set_pow4(pbf_oracle *o, int on) {
   dispatch(o, [&](auto &s) { s.pow4 = on != 0; return 0; });
 }
 
+// ---- scene dynamics on the host side of advance() (ompsph.hpp:91-126, 167-186) ------------------------------
+// sources[k] = {centre.xyz, velocity.xyz, colour.rgba, rate} (11 doubles), tags[k] = Source::tag
+int pbf_oracle_scene_emit(pbf_oracle *o, double h, double scale, size_t n_sources, const uint64_t *tags,
+                          const double *sources) {
+  return dispatch(o, [&](auto &s) {
+    using N = std::decay_t<decltype(s.mass[0])>;
+    const N spacing = (N(h) * N(scale) / 2);  // ompsph.hpp:93
+    for (size_t k = 0; k < n_sources; ++k) {
+      const double *q = sources + 11 * k;
+      const V3<N> centre{N(q[0]), N(q[1]), N(q[2])}, velocity{N(q[3]), N(q[4]), N(q[5])};
+      const V4<N> colour{N(q[6]), N(q[7]), N(q[8]), N(q[9])};
+      const N size = std::sqrt(static_cast<N>(q[10]));  // ompsph.hpp:95
+      const size_t width = size_t(std::floor(size)), depth = size_t(std::ceil(size));
+      // offset = centre - (V3(width, 0, depth) * 0.5 * spacing)                                   ompsph.hpp:98
+      const V3<N> half{N(width) * N(0.5) * spacing, N(0) * N(0.5) * spacing, N(depth) * N(0.5) * spacing};
+      const V3<N> offset = centre - half;
+      for (size_t x = 0; x < width; ++x)
+        for (size_t z = 0; z < depth; ++z) {
+          const V3<N> step{N(x) * spacing, N(0) * spacing, N(z) * spacing};
+          s.id.push_back(tags[k]);
+          s.type.push_back(0);
+          s.mass.push_back(N(1));
+          s.pos.push_back(offset + step);
+          s.vel.push_back(velocity);
+          s.colour.push_back(colour);
+        }
+    }
+    const size_t n = s.id.size();
+    s.zIndex.assign(n, 0), s.pStar.assign(n, {}), s.deltaP.assign(n, {}), s.lambda.assign(n, N(0));
+    return 0;
+  });
+}
+
+// drains[k] = {centre.xyz, width}: fluid strictly closer than `width` to a drain centre is erased, obstacles stay
+int pbf_oracle_scene_drain(pbf_oracle *o, size_t n_drains, const double *drains) {
+  return dispatch(o, [&](auto &s) {
+    using N = std::decay_t<decltype(s.mass[0])>;
+    size_t w = 0;
+    for (size_t a = 0; a < s.id.size(); ++a) {
+      bool gone = false;
+      if (s.type[a] != 1)  // ompsph.hpp:109
+        for (size_t k = 0; k < n_drains && !gone; ++k) {
+          const double *q = drains + 4 * k;
+          const V3<N> d = s.pos[a] - V3<N>{N(q[0]), N(q[1]), N(q[2])};  // glm::distance = length(b - a)
+          gone = std::sqrt(d.x * d.x + d.y * d.y + d.z * d.z) < N(q[3]);
+        }
+      if (!gone) {
+        s.id[w] = s.id[a], s.type[w] = s.type[a], s.mass[w] = s.mass[a], s.pos[w] = s.pos[a], s.vel[w] = s.vel[a];
+        s.colour[w] = s.colour[a];
+        ++w;
+      }
+    }
+    s.id.resize(w), s.type.resize(w), s.mass.resize(w), s.pos.resize(w), s.vel.resize(w), s.colour.resize(w);
+    s.zIndex.assign(w, 0), s.pStar.assign(w, {}), s.deltaP.assign(w, {}), s.lambda.assign(w, N(0));
+    return 0;
+  });
+}
+
+// ids of the FLUID particles in the cell of a query point, in sorted order (ompsph.hpp:167-186); needs sort +
+// grid_table of the current step.  Returns the count, writes at most `cap` ids.
+size_t pbf_oracle_query(const pbf_oracle *o, const pbf_oracle_params *p, const double point[3], uint64_t *out, size_t cap) {
+  return dispatch(o, [&](const auto &s) -> size_t {
+    using N = std::decay_t<decltype(s.mass[0])>;
+    const N h = N(p->h), scale = N(p->scale);
+    const V3<N> scaled = V3<N>{N(point[0]), N(point[1]), N(point[2])} / scale - s.minExtent;
+    using S = std::decay_t<decltype(s)>;  // zCurveGridIndexAtCoordAt (sph.hpp:198-201)
+    const uint64_t z = mortonEncode(S::cellCoord(scaled.x / h), S::cellCoord(scaled.y / h), S::cellCoord(scaled.z / h));
+    const uint64_t tn = s.table.size();
+    size_t k = 0;
+    if (z < tn && z + 1 < tn)
+      for (uint64_t a = s.table[z]; a < s.table[z + 1]; ++a) {
+        if (s.type[a] != 0) continue;
+        if (k < cap) out[k] = s.id[a];
+        ++k;
+      }
+    return k;
+  });
+}
+
 const char *pbf_oracle_last_error(void) { return g_err.c_str(); }
 
 }  // extern "C"

@@ -132,6 +132,15 @@ void pbf_oracle_set_pow4(pbf_oracle *, int on);
 
 const char *pbf_oracle_last_error(void);
 
+/* Scene dynamics on the host side of advance() (ompsph.hpp:91-126, 167-186): sources emit a floor(sqrt(rate)) x
+ * ceil(sqrt(rate)) sheet at spacing h*scale/2, drains erase fluid closer than `width`, a query lists the fluid ids
+ * in the cell of a point (after sort + grid_table).  sources[k] = {centre.xyz, velocity.xyz, colour.rgba, rate},
+ * drains[k] = {centre.xyz, width}. */
+int pbf_oracle_scene_emit(pbf_oracle *, double h, double scale, size_t n_sources, const uint64_t *tags,
+                          const double *sources);
+int pbf_oracle_scene_drain(pbf_oracle *, size_t n_drains, const double *drains);
+size_t pbf_oracle_query(const pbf_oracle *, const pbf_oracle_params *, const double point[3], uint64_t *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <set>
+#include <string>
 
 #include "hipsph.hpp"
 
@@ -27,7 +28,53 @@ static int failures = 0;
     }                                           \
   } while (0)
 
-int main() {
+// --dump <dir>: one fixed scene with sources, a drain, an obstacle and queries run through advance() for two frames;
+// the particles and the query answers after each frame go to <dir> as raw arrays.  tests/test_cli_gpu.py replays the
+// same scene through the ORACLE's restatement of ompsph.hpp:91-126,167-186 and expects identical ids, order and bits.
+static int dump_scene(const char *dir) {
+  auto [mc, config, particles] = sph::simpleConfigWith2Cubes<T, N, sph::vec>(2048, 4, N(500));
+  (void)mc;
+  sph::hip_impl::Solver<T, N> solver(N(0.1));
+  auto xs = particles;
+  xs[7].type = sph::Type::Obstacle;
+  sph::Scene<T, N, sph::vec> scene;
+  scene.sources.push_back({T(100777), V3(500, 300, 500), V3(0, 1, 0), V4(1, 0, 0, 1), N(16)});
+  scene.sources.push_back({T(100888), V3(200, 700, 800), V3(3, 0, -2), V4(0, 1, 0, 1), N(10)});
+  scene.drains.push_back({T(1), xs[7].position, N(60), N(0)});
+  scene.queries.push_back({T(5), xs[100].position});
+  scene.queries.push_back({T(6), V3(990, 990, 990)});
+  scene.queries.push_back({T(7), V3(510, 310, 510)});
+  for (int frame = 0; frame < 2; ++frame) {
+    const auto res = solver.advance(config, scene, xs);
+    const std::string base = std::string(dir) + "/frame" + std::to_string(frame);
+    FILE *f = std::fopen((base + "_particles.bin").c_str(), "wb");
+    if (!f) return 2;
+    const uint64_t n = xs.size();
+    std::fwrite(&n, 8, 1, f);
+    for (const auto &p : xs) {
+      const uint64_t id = p.id;
+      const uint8_t ty = uint8_t(p.type);
+      std::fwrite(&id, 8, 1, f), std::fwrite(&ty, 1, 1, f), std::fwrite(&p.position, sizeof(N), 3, f);
+      std::fwrite(&p.velocity, sizeof(N), 3, f), std::fwrite(&p.colour, sizeof(N), 4, f);
+    }
+    std::fclose(f);
+    f = std::fopen((base + "_queries.bin").c_str(), "wb");
+    for (const auto &q : res.queries) {
+      const uint64_t qid = q.id, cnt = q.neighbours.size();
+      std::fwrite(&qid, 8, 1, f), std::fwrite(&cnt, 8, 1, f);
+      for (T v : q.neighbours) {
+        const uint64_t id = v;
+        std::fwrite(&id, 8, 1, f);
+      }
+    }
+    std::fclose(f);
+  }
+  std::printf("dumped\n");
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc == 3 && std::string(argv[1]) == "--dump") return dump_scene(argv[2]);
   auto [mc, config, particles] = sph::simpleConfigWith2Cubes<T, N, sph::vec>(2048, 4, N(500));
   (void)mc;
   sph::hip_impl::Solver<T, N> solver(N(0.1));

@@ -126,6 +126,10 @@ def _bind(L):
                                                   C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.pbf_oracle_get_lattice.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pbf_oracle_get_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pbf_oracle_scene_emit.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.pbf_oracle_scene_drain.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.pbf_oracle_query.restype = C.c_size_t
+    L.pbf_oracle_query.argtypes = [C.c_void_p, C.POINTER(OracleParams), C.c_void_p, C.c_void_p, C.c_size_t]
     return L
 
 
@@ -299,6 +303,26 @@ class Oracle:
         pn, cc = np.empty((nn, 4), self.dtype), np.empty((nn, 4), self.dtype)
         self.L.pbf_oracle_get_lattice(self.h, _vp(smp), _vp(pn), _vp(cc))
         return dict(vs=vs, ns=ns, cs=cs, sample=smp, pn=pn, c=cc)
+
+    # -- scene dynamics on the host side of advance() (ompsph.hpp:91-126, 167-186) --
+    def emit(self, sources, h=0.1, scale=500.0):
+        """sources: list of (tag, centre3, velocity3, colour4, rate)"""
+        tags = np.array([s[0] for s in sources], np.uint64)
+        rows = np.array([list(s[1]) + list(s[2]) + list(s[3]) + [s[4]] for s in sources], np.float64)
+        self.L.pbf_oracle_scene_emit(self.h, h, scale, len(sources), _vp(tags), _vp(rows))
+        return self
+
+    def drain(self, drains):
+        """drains: list of (centre3, width)"""
+        rows = np.array([list(d[0]) + [d[1]] for d in drains], np.float64)
+        self.L.pbf_oracle_scene_drain(self.h, len(drains), _vp(rows))
+        return self
+
+    def query(self, p, point):
+        pt = np.array(point, np.float64)
+        out = np.empty(4096, np.uint64)
+        k = self.L.pbf_oracle_query(self.h, C.byref(p), _vp(pt), _vp(out), len(out))
+        return out[:k].copy()
 
     def table(self):
         t = np.empty(self.L.pbf_oracle_table_size(self.h), np.uint64)

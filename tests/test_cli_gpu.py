@@ -79,6 +79,48 @@ def test_cpp_shim_sources_drains_queries():
         assert f"ok {name}" in r.stdout, r.stdout
 
 
+def test_shim_scene_dynamics_vs_oracle(pkg, oracle, tmp_path):
+    """Sources, drains, an obstacle and queries through hip_impl::Solver::advance() (host/hipsph.hpp) for two frames
+    against the ORACLE's restatement of ompsph.hpp:91-126,167-186 (pbf_oracle_scene_emit / _drain / _query): the
+    same particles in the same order with the same bits, the same query answers."""
+    r = subprocess.run([os.path.join(ROOT, "pbf-sph_amd", "test_shim"), "--dump", str(tmp_path)], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "dumped" in r.stdout, r.stdout + r.stderr
+    sc = pkg.scene_cubes(2048)
+    sc = {k: v.copy() for k, v in sc.items()}
+    sc["type"][7] = 1
+    o = oracle.Oracle(False, device_pow=True)
+    o.set_particles(**sc)
+    q = oracle.make_params(iteration=4, mode=oracle.JACOBI, sort=oracle.SORT_STABLE)
+    sources = [(100777, (500, 300, 500), (0, 1, 0), (1, 0, 0, 1), 16.0), (100888, (200, 700, 800), (3, 0, -2), (0, 1, 0, 1), 10.0)]
+    drains = [(tuple(float(v) for v in sc["pos"][7]), 60.0)]
+    points = [(5, tuple(float(v) for v in sc["pos"][100])), (6, (990.0, 990.0, 990.0)), (7, (510.0, 310.0, 510.0))]
+    rec = np.dtype([("id", "<u8"), ("type", "u1"), ("pos", "<f4", 3), ("vel", "<f4", 3), ("colour", "<f4", 4)])
+    for frame in range(2):
+        o.emit(sources).drain(drains)
+        o.predict(q).sort(q).grid_table(q)
+        answers = [o.query(q, pt) for _, pt in points]
+        o.diffuse(q)
+        for _ in range(4):
+            o.lambda_(q).delta(q)
+        o.finalise(q)
+        w = o.get_particles()
+        raw = open(tmp_path / f"frame{frame}_particles.bin", "rb").read()
+        n = int(np.frombuffer(raw[:8], np.uint64)[0])
+        g = np.frombuffer(raw[8:], rec)
+        assert n == len(w["id"]) == len(g), (frame, n, len(w["id"]))
+        for k in ("id", "type", "pos", "vel", "colour"):
+            assert np.array_equal(g[k], w[k]), (frame, k)
+        qraw = np.frombuffer(open(tmp_path / f"frame{frame}_queries.bin", "rb").read(), np.uint64)
+        at = 0
+        for (qid, _), want in zip(points, answers):
+            assert qraw[at] == qid and qraw[at + 1] == len(want), (frame, qid, qraw[at + 1], len(want))
+            assert np.array_equal(qraw[at + 2:at + 2 + len(want)], want)
+            at += 2 + len(want)
+        assert at == len(qraw)
+    assert (w["id"] == 100777).sum() == 32 and (w["id"] == 100888).sum() == 24   # two frames of 16 + 12
+
+
 def test_cli_slabs(tmp_path):
     """--slabs K: hip_impl::Solver(h, {devices...}) — K x-slabs behind the same CLI, pbf_slab_step per slab on its own
     host thread, exchange inside the library (in-process transport here: the slabs share this GPU; --all-devices on
