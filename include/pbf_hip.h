@@ -79,7 +79,7 @@ void pbf_destroy(pbf_ctx *ctx);
 const char *pbf_last_error(const pbf_ctx *ctx);
 int pbf_abi_version(void);
 /* Tuning / diagnostic knobs (no reference counterpart): "gather" (0 global walk, 1 filtered lists, 2 LDS bricks),
- * "list_max", "tile_cap", "reuse_lists", "split_build" (0 lambda builds the lists itself, 1-5 list-build launch variants,
+ * "list_max", "tile_cap", "reuse_lists", "split_build" (0 lambda builds the lists itself, 4 / 5 list-build launch with 2 / 4 pair loads per trip,
  * default 5), "coop" (0 = one lane per particle in the list-driven lambda / delta-p, bit-exact, default; 2 / 4 / 8 = that many
  * lanes share a particle's list and reduce the kernel sums with wave shuffles: rounding-level differences),
  * "cell_diffuse" (one colour walk per occupied cell, default 1), "fuse_diffuse", "timing_mask" (bit i = stage i of pbf_stage_times is bracketed with events).

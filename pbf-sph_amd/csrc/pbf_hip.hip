@@ -101,9 +101,9 @@ struct pbf_ctx {
   bool haveParams = false;
   bool qposValid = false;    // qpos is the quantised copy of pstar[pcur] (written by the sort, delta-p and the slab refresh)
   bool reuseLists = true;    // option "reuse_lists"
-  // option "split_build": 0 = lambda builds the neighbour lists while it gathers (k_gather_lists<SAVE>);
-  // otherwise the build is a launch of its own followed by a list-driven lambda: 1 = k_gather_lists build-only,
-  // 2 / 3 = k_build_lists 4- / 8-way on fp pStar, 4 / 5 = k_build_lists_q (quantised pairs) 2 / 4 loads per trip
+  // option "split_build": 0 = lambda builds the neighbour lists while it gathers (k_gather_lists<SAVE>); otherwise the
+  // build is a launch of its own (k_build_lists_q on quantised pairs: 4 = 2 loads per trip, anything else = 4 loads per
+  // trip) followed by a list-driven lambda.  (Round 1's intermediate build kernels, values 1-3, are gone.)
   int splitBuild = 5;
   int pipeline = -1;         // option "pipeline": software-pipelined list readers (bit-identical either way); -1 = auto:
                              // fp64 only (measured at 1 M: fp64 -1.3 %, fp32 +3 % — fp32's readers are VALU-issue bound)
@@ -470,25 +470,17 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
       from_lists();
     } else if (mode == GATHER_SAVE_LISTS && ctx->splitBuild &&
                uint64_t(ctx->n) * sizeof(typename Op::Src) <= 0xFFFFFFFFull) {  // (k_build_lists: 32-bit offsets)  // build the lists, then run the op list-driven
-      if (ctx->splitBuild == 1)
-        hipLaunchKernelGGL((k_gather_lists<N, Op, 16, true, NoExtra, true>), g, b, 0, ctx->stream, c, args, key, table,
-                           nl, nc, NoExtra::Args{});
-      else if constexpr (Op::kTileable && Op::kFilter) {  // (the ops that filter on pStar itself: lambda, delta-p)
-        if (ctx->splitBuild >= 4) {
-          uint2 *qp = ctx->qpos.as<uint2>();
-          if (!ctx->qposValid) {  // (only after a stage that moved pStar without refreshing its quantised copy)
-            hipLaunchKernelGGL((k_quantise<N>), g, b, 0, ctx->stream, c, Op::src(args), qp);
-            ctx->qposValid = true;
-          }
-          StageTimer tb(ctx, ST_BUILD);
-          if (ctx->splitBuild == 4)
-            hipLaunchKernelGGL((k_build_lists_q<N, 2>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc);
-          else
-            hipLaunchKernelGGL((k_build_lists_q<N, 4>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc);
-        } else if (ctx->splitBuild == 2)
-          hipLaunchKernelGGL((k_build_lists<N, 4>), g, b, 0, ctx->stream, c, Op::src(args), args.type, key, table, nl, nc);
+      if constexpr (Op::kTileable && Op::kFilter) {  // (the ops that filter on pStar itself: lambda, delta-p)
+        uint2 *qp = ctx->qpos.as<uint2>();
+        if (!ctx->qposValid) {  // (only after a stage that moved pStar without refreshing its quantised copy)
+          hipLaunchKernelGGL((k_quantise<N>), g, b, 0, ctx->stream, c, Op::src(args), qp);
+          ctx->qposValid = true;
+        }
+        StageTimer tb(ctx, ST_BUILD);
+        if (ctx->splitBuild == 4)
+          hipLaunchKernelGGL((k_build_lists_q<N, 2>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc);
         else
-          hipLaunchKernelGGL((k_build_lists<N, 8>), g, b, 0, ctx->stream, c, Op::src(args), args.type, key, table, nl, nc);
+          hipLaunchKernelGGL((k_build_lists_q<N, 4>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc);
       }
       from_lists();
     } else if (mode == GATHER_SAVE_LISTS) {

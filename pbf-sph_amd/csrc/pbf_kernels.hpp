@@ -1123,8 +1123,7 @@ constexpr uint32_t NBR_OVERFLOW = 0xFFFFFFFFu;
 struct NoExtra {
   struct Args {};
 };
-// BUILD_ONLY: only build and save the lists (no pair terms, no output) — the op then runs list-driven.
-template <typename N, typename Op, int LMAX, bool SAVE = false, typename Extra = NoExtra, bool BUILD_ONLY = false>
+template <typename N, typename Op, int LMAX, bool SAVE = false, typename Extra = NoExtra>
 __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typename Op::Args args,
                                                         const uint32_t *__restrict__ key,
                                                         const uint32_t *__restrict__ table,
@@ -1157,7 +1156,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
       const bool valid = q < nl;
       const uint32_t b = valid ? list[q * BLOCK + tid] : i;
       if (SAVE && valid && written + q < NBR_CAP) mine[(written + q) * BLOCK] = b;
-      if (!BUILD_ONLY) op.add_bf(c, Op::load(args, b), valid);
+      op.add_bf(c, Op::load(args, b), valid);
     }
     written += nl;
     nl = 0;
@@ -1208,109 +1207,11 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
     }
   drain();
   if (SAVE) nbrCount[i] = written <= NBR_CAP ? written : NBR_OVERFLOW;
-  if (!BUILD_ONLY) op.end(c, args, i);
+  op.end(c, args, i);
   if constexpr (FUSED) extra.end(c, xargs, i);
 }
 
-// Neighbour-list build on its own (no pair terms): the walk is latency-bound — table entry ->
-// candidate position -> test, 27 times in a row — so this kernel is shaped for loads in flight:
-//   * the three x-cells of a (dy, dz) row are walked as ONE candidate sequence (two runs of the sorted
-//     array, slot -> index by one compare; order unchanged: x fastest), WAYS candidates per trip, so
-//     a row of ~12 candidates costs two trips of eight loads instead of six trips of four;
-//   * the next row's six table entries are loaded before the current row is walked;
-//   * no accumulators: survivors of the conservative test are staged per lane in LDS and flushed to
-//     the block's [slot][thread] list in HBM a slot at a time (one dense store per slot; a store per
-//     hit was measured 20 % slower), which lambda and delta-p then both read (k_gather_from_lists).
-template <typename N, int WAYS, int LMAX = 16>
-__global__ __launch_bounds__(BLOCK) void k_build_lists(StepConsts<N> c, const vec4<N> *__restrict__ pstar,
-                                                       const uint8_t *__restrict__ type,
-                                                       const uint32_t *__restrict__ key,
-                                                       const uint32_t *__restrict__ table,
-                                                       uint32_t *__restrict__ nbrList,
-                                                       uint32_t *__restrict__ nbrCount) {
-  __shared__ uint32_t list[(LMAX + WAYS) * BLOCK];  // per-lane staging: a trip appends up to WAYS past LMAX - 1
-  const uint32_t tid = threadIdx.x;
-  const uint32_t i = blockIdx.x * BLOCK + tid;
-  if (i >= c.n) return;
-  if (c.hasObstacles && type[i] != 0) {  // obstacles and ghost copies gather nothing (the ops' begin() agrees)
-    nbrCount[i] = 0;
-    return;
-  }
-  // 32-bit byte offsets from a uniform base (the host checks n * sizeof(vec4) < 2^32): one shift per address
-  const char *pbase = reinterpret_cast<const char *>(pstar);
-  auto position = [&](uint32_t b) { return *reinterpret_cast<const vec4<N> *>(pbase + b * uint32_t(sizeof(vec4<N>))); };
-  const vec4<N> pa = position(i);
-  uint32_t *blk = nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK;
-  uint32_t written = 0, nl = 0;
-  // staged survivors go out together: entry q of every lane in one store instruction (wave-uniform trip count)
-  auto flush = [&]() {
-    for (uint32_t q = 0; __any(q < nl); ++q)
-      if (q < nl && written + q < NBR_CAP) blk[(written + q) * BLOCK + tid] = list[q * BLOCK + tid];
-    written += nl;
-    nl = 0;
-  };
-  const Neigh nb = neigh_codes(key[i]);
-  struct Row {
-    uint32_t s[3], e[3];
-  };
-  auto load_row = [&](int r) {
-    Row row;
-    const uint32_t yz = nb.ys[r % 3] | nb.zs[r / 3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const uint32_t code = nb.xs[dx] | yz;
-      row.s[dx] = row.e[dx] = 0;
-      if (code < c.tableN) {  // sph.hpp:206-208
-        row.s[dx] = table[code];
-        row.e[dx] = (code + 1u) < c.tableN ? table[code + 1u] : row.s[dx];
-      }
-    }
-    return row;
-  };
-  bool irregular = false;
-  Row next = load_row(0);
-#pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    const Row row = next;
-    if (r < 8) next = load_row(r + 1);
-    // The row's three cells are at most TWO runs of the sorted array: x cells (2m, 2m + 1) have adjacent
-    // codes, so either (x-1, x) or (x, x+1) is one contiguous range.  Empty / out-of-table cells drop out.
-    const uint32_t l0 = row.e[0] - row.s[0], l1 = row.e[1] - row.s[1], l2 = row.e[2] - row.s[2];
-    uint32_t sA, lA, sB, lB;
-    if (l0 == 0u) sA = row.s[1], lA = l1, sB = row.s[2], lB = l2;
-    else if (row.e[0] == row.s[1]) sA = row.s[0], lA = l0 + l1, sB = row.s[2], lB = l2;
-    else if (l1 == 0u) sA = row.s[0], lA = l0, sB = row.s[2], lB = l2;
-    else {
-      sA = row.s[0], lA = l0, sB = row.s[1], lB = l1 + l2;
-      irregular |= (l2 != 0u) && (row.e[1] != row.s[2]);  // cannot happen with a Morton table; see below
-    }
-    const uint32_t L = lA + lB, oB = sB - lA;  // slot -> index: slot + (slot < lA ? sA : oB), x fastest as before
-    for (uint32_t t = 0; __any(t < L); t += WAYS) {
-      if (t < L) {
-        uint32_t b[WAYS];
-        vec4<N> cnd[WAYS];
-#pragma unroll
-        for (uint32_t w = 0; w < WAYS; ++w) {
-          const uint32_t sl = min(t + w, L - 1u);  // a tail slot re-reads the last candidate and is masked
-          b[w] = sl + (sl < lA ? sA : oB);
-          cnd[w] = position(b[w]);
-        }
-#pragma unroll
-        for (uint32_t w = 0; w < WAYS; ++w) {
-          const bool hit = (t + w < L) & maybe_within_h<N>(pa, cnd[w], c.h2filter);
-          list[nl * BLOCK + tid] = b[w];  // branch-free append: the slot is kept only on a hit
-          nl += hit ? 1u : 0u;
-        }
-      }
-      if (__any(nl >= uint32_t(LMAX))) flush();
-    }
-  }
-  flush();
-  // a row that is not two runs (never with a table built by stage_sort) falls back to the cell walk
-  nbrCount[i] = (written <= NBR_CAP && !irregular) ? written : NBR_OVERFLOW;
-}
-
-// ---- the same build on 8-byte quantised positions -------------------------------------------------
+// Neighbour-list build on its own (no pair terms), on 8-byte quantised positions -------------------------------
 // The build is bound by the texture-address path (64 lanes x 16 B per candidate load), so the test
 // runs on a compact copy of pStar: per axis the LOW 16 bits of floor((p - gridMin) * 2048 / h).
 // Differences are taken modulo 2^16 (v_pk_sub_i16), i.e. exact whenever the true separation is below

@@ -1,5 +1,6 @@
-"""Slab decomposition of the PBF-SPH step across GPUs: one process per GPU, RCCL over xGMI through
-torch.distributed (backend "nccl"); the same driver runs on CPU tensors with "gloo" for tests.
+"""Slab decomposition of the PBF-SPH step across GPUs: one rank per GPU.  CSlabSolver (production) attaches a
+communicator and lets libpbf_hip.so run the whole step incl. the RCCL send/recv exchange (pbf_slab_step); SlabSolver
+is the same protocol sequenced in Python for the CPU twin the tests compare against.
 
 The reference is single-device — this layer has no counterpart there; its
 correctness statement is "N ranks == 1 rank".  Layout: rank g owns the cell columns
@@ -278,25 +279,24 @@ class CSlabSolver:
 
 
 class SlabSolver:
-    """Sequences one rank's share of the step and the neighbour exchanges.
+    """The slab protocol sequenced in Python, one engine call per phase: the readable twin of pbf_slab_step
+    (csrc/pbf_hip.hip slab_step_impl).  The tests run it with the CPU oracle as the engine (tests/slab_engines.py,
+    gloo, no GPU needed) and hold the library's step to its results bit for bit; with HipEngine it drives the
+    library's low-level pbf_slab_* entry points (wire buffers bounced through host tensors).  Production runs
+    CSlabSolver: the whole step and its RCCL exchanges inside libpbf_hip.so.
 
-    engine : HipEngine (GPU) — tests plug a CPU engine with the same methods
+    engine : OracleEngine / HipEngine
     dist   : torch.distributed (initialised), or None for a single rank
     cuts   : nranks + 1 column boundaries, identical on every rank
     """
 
-    def __init__(self, engine, dist, rank, nranks, cuts, cap_records, stage_via_host=False, rebalance_every=0):
-        # stage_via_host: bounce the wire buffers through CPU tensors (lets several ranks share ONE GPU
-        # under the "gloo" backend for tests; production uses "nccl" = RCCL straight from device memory)
+    def __init__(self, engine, dist, rank, nranks, cuts, cap_records, stage_via_host=True, rebalance_every=0):
         self.e, self.dist, self.rank, self.nranks = engine, dist, rank, nranks
-        self.stage_via_host = stage_via_host
         self.set_cuts(cuts)  # also switches the engine to rank-local keys
         self.cap = int(cap_records)
         big = max(engine.record_bytes(REC_MIGRANT), engine.record_bytes(REC_GHOST))
         self.send = [engine.alloc(self.cap * big) for _ in range(2)]
         self.recv = [engine.alloc(self.cap * big) for _ in range(2)]
-        self.cnt_send = [engine.alloc(8) for _ in range(2)]
-        self.cnt_recv = [engine.alloc(8) for _ in range(2)]
         self.sent = [0, 0]
         self.got = [0, 0]
         self.stats = dict(migrated=0, ghosts=0, exchanges=0, recuts=0)
@@ -313,28 +313,23 @@ class SlabSolver:
             self.e.configure(self.cut, self.cuts[self.rank - 1] if self.left is not None else 0,
                              self.cuts[self.rank + 1] if self.right is not None else 0)
 
-    # -- neighbour exchange -----------------------------------------------------------------------
+    # -- neighbour exchange (host tensors over gloo) ------------------------------------------------
     def _exchange(self, send_bytes, recv_bytes):
         """One batched point-to-point round: send_bytes/recv_bytes = (left, right) byte counts."""
         if self.dist is None or self.nranks == 1:
             return
+        t = self.e.torch
         ops, back = [], []
         for side, peer in ((0, self.left), (1, self.right)):
             if peer is None:
                 continue
             if recv_bytes[side]:
-                dst = self.recv[side][:recv_bytes[side]]
-                if self.stage_via_host:
-                    host = self.e.torch.empty(recv_bytes[side], dtype=self.e.torch.uint8)
-                    back.append((dst, host))
-                    dst = host
-                ops.append(self.dist.P2POp(self.dist.irecv, dst, peer))
+                host = t.empty(recv_bytes[side], dtype=t.uint8)
+                back.append((self.recv[side][:recv_bytes[side]], host))
+                ops.append(self.dist.P2POp(self.dist.irecv, host, peer))
             if send_bytes[side]:
-                src = self.send[side][:send_bytes[side]]
-                if self.stage_via_host:
-                    self.e.sync()
-                    src = src.cpu()
-                ops.append(self.dist.P2POp(self.dist.isend, src, peer))
+                self.e.sync()
+                ops.append(self.dist.P2POp(self.dist.isend, self.send[side][:send_bytes[side]].cpu(), peer))
         if ops:
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
@@ -346,30 +341,20 @@ class SlabSolver:
         if self.dist is None or self.nranks == 1:
             return 0, 0
         t = self.e.torch
-        ops = []
+        ops, got = [], {}
         for side, peer, n in ((0, self.left, n_l), (1, self.right, n_r)):
             if peer is None:
                 continue
-            if self.stage_via_host:
-                self.cnt_send[side] = t.tensor([n], dtype=t.int64)
-                self.cnt_recv[side] = t.zeros(1, dtype=t.int64)
-                ops.append(self.dist.P2POp(self.dist.irecv, self.cnt_recv[side], peer))
-                ops.append(self.dist.P2POp(self.dist.isend, self.cnt_send[side], peer))
-            else:
-                self.cnt_send[side][:8].copy_(t.tensor([n], dtype=t.int64).view(t.uint8))
-                ops.append(self.dist.P2POp(self.dist.irecv, self.cnt_recv[side][:8], peer))
-                ops.append(self.dist.P2POp(self.dist.isend, self.cnt_send[side][:8], peer))
+            got[side] = t.zeros(1, dtype=t.int64)
+            ops.append(self.dist.P2POp(self.dist.irecv, got[side], peer))
+            ops.append(self.dist.P2POp(self.dist.isend, t.tensor([n], dtype=t.int64), peer))
         for w in self.dist.batch_isend_irecv(ops):
             w.wait()
-        out = [0, 0]
-        for side, peer in ((0, self.left), (1, self.right)):
-            if peer is not None:
-                c = self.cnt_recv[side] if self.stage_via_host else self.cnt_recv[side][:8].view(t.int64).cpu()
-                out[side] = int(c[0])
-        return out[0], out[1]
+        return int(got[0][0]) if 0 in got else 0, int(got[1][0]) if 1 in got else 0
 
     def _swap(self, kind, n_l, n_r):
-        """Tell the neighbours how many records come, then move them. Returns (from_left, from_right)."""
+        """Tell the neighbours how many records come, then move them. Returns (from_left, from_right).
+        (pbf_slab_step carries the counts in the message header instead: no count round trip.)"""
         g_l, g_r = self._exchange_counts(n_l, n_r)
         if max(g_l, g_r) > self.cap:
             raise RuntimeError(f"slab wire buffer too small: {max(g_l, g_r)} records > cap {self.cap}")
@@ -385,8 +370,6 @@ class SlabSolver:
             return False
         t = self.e.torch
         h = t.from_numpy(self.e.column_histogram())
-        if self.dist.get_backend() == "nccl":
-            h = h.to(self.e.device)
         self.dist.all_reduce(h)
         new = recut(self.cuts, h.cpu().numpy())
         if new != self.cuts:

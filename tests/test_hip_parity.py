@@ -139,10 +139,10 @@ def test_free_running_bit_exact(pkg, oracle, scene, fp64, variant):
             assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
 
 
-@pytest.mark.parametrize("split,fp64", [(0, False), (3, False), (5, False), (0, True), (5, True)])
+@pytest.mark.parametrize("split,fp64", [(0, False), (4, False), (5, False), (0, True), (5, True)])
 def test_split_build_bit_exact(pkg, oracle, split, fp64):
-    """Option split_build: 0 = lambda builds the neighbour lists while it gathers; 1..3 = a list-build launch of
-    its own (k_gather_lists build-only / k_build_lists 4- and 8-way) followed by a list-driven lambda.  Same
+    """Option split_build: 0 = lambda builds the neighbour lists while it gathers; 4 / 5 = a list-build launch of
+    its own (k_build_lists_q, 2 / 4 pair loads per trip) followed by a list-driven lambda.  Same
     candidates in the same order either way — identical bits, obstacles and overflow rows included."""
     sc, side = get_scene(pkg, "dam8192", fp64)
     sc = {k: v.copy() for k, v in sc.items()}
