@@ -111,7 +111,12 @@ int pbf_download_aos(pbf_ctx *ctx, void *particles, const pbf_aos_layout *layout
  * -> finalise.  The two loops the reference updates in place (racy with >1 thread,
  * src/omp/ompsph.hpp:188-207,235-248) are double-buffered (Jacobi) here. */
 int pbf_step(pbf_ctx *ctx, const pbf_params *params);
-int pbf_steps(pbf_ctx *ctx, const pbf_params *params, uint32_t count); /* count x pbf_step, no host sync */
+/* count x pbf_step, no host sync.  Each distinct step (same buffer roles, same parameters) is captured into a hipGraph
+ * the first time it comes by and replayed afterwards: one graph launch instead of ~25 kernel launches (option "graph",
+ * default 1).  Stage timing, wells, slab mode, a step that still allocates and scenes whose parameters change every
+ * frame (the stock moving box) run eagerly; results are identical either way. */
+int pbf_steps(pbf_ctx *ctx, const pbf_params *params, uint32_t count);
+int pbf_graph_stats(const pbf_ctx *ctx, uint64_t out[3]); /* {graphs captured, graph replays, graphs still enabled} */
 int pbf_sync(pbf_ctx *ctx);
 
 /* Stage-level entry points: exactly the launches pbf_step makes, exposed so that each kernel

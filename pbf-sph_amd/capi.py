@@ -112,6 +112,7 @@ _SIGS = {
     "pbf_step": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "pbf_steps": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_uint32]),
     "pbf_sync": (C.c_int, [C.c_void_p]),
+    "pbf_graph_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pbf_stage_predict": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "pbf_stage_sort": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "pbf_stage_diffuse": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
@@ -291,6 +292,12 @@ class Solver:
     def sync(self):
         self._chk(self.L.pbf_sync(self.ctx), "pbf_sync")
         return self
+
+    def graph_stats(self):
+        """(graphs captured, graph replays, graphs still enabled) of pbf_steps' hipGraph path"""
+        o = np.zeros(3, np.uint64)
+        self._chk(self.L.pbf_graph_stats(self.ctx, _vp(o)), "pbf_graph_stats")
+        return int(o[0]), int(o[1]), bool(o[2])
 
     def stage(self, name, p):
         self._chk(getattr(self.L, "pbf_stage_" + name)(self.ctx, C.byref(p)), "pbf_stage_" + name)

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -46,6 +47,31 @@ struct EventPair {
 };
 
 }  // namespace
+
+// hipGraph replay of the resident step (option "graph"): everything host-side that one step reads AND leaves behind —
+// which physical buffer plays which role, the validity flags — so that a replayed graph can put the context into the
+// state the captured step left it in.  Also the key under which a captured step is found again.
+struct StepState {
+  int cur, pcur;
+  uint32_t flags;  // sorted | counted << 1 | nbrValid << 2 | qposValid << 3 | hasObstacles << 4
+  uint32_t tableN, countedTableN, gatherSeq;
+  uint64_t extent[3];
+  double minExtent[3];
+  void *bufs[15];  // pos4[2] vel4[2] col4[2] id[2] type[2] key[2] pstar[3]
+  size_t caps[15];
+  bool operator<(const StepState &o) const { return std::memcmp(this, &o, sizeof(StepState)) < 0; }
+};
+struct GraphEntry {
+  hipGraphExec_t exec = nullptr;
+  StepState after;
+};
+struct GraphKey {
+  StepState before;
+  unsigned char params[sizeof(double) * 11 + 32];  // dt, scale, force, bounds, iteration, xsph, vorticity
+  uint64_t n;
+  int options[10];
+  bool operator<(const GraphKey &o) const { return std::memcmp(this, &o, sizeof(GraphKey)) < 0; }
+};
 
 struct pbf_ctx {
   pbf_desc desc{};
@@ -97,6 +123,13 @@ struct pbf_ctx {
   void *regPtr = nullptr;
   size_t regBytes = 0;
   size_t stagedBytes = 0;  // bytes of `staging` that hold a defined AoS image (padding bytes of a download come from it)
+  // option "graph" (default on): pbf_steps replays each distinct step as a captured hipGraph (one graph launch instead
+  // of ~25 kernel launches); stage timing, wells, growing buffers or a box that moves every frame fall back to eager
+  int graphMode = 1;
+  std::map<GraphKey, GraphEntry> graphs;
+  uint64_t allocEpoch = 0;     // bumped by every hipMalloc of ensure(): a step that allocated is not captured
+  uint32_t graphMisses = 0;    // captures without a replay in between: a scene that never repeats turns graphs off
+  uint64_t graphReplays = 0, graphCaptures = 0;
   pbf_params lastParams{};   // the params of the last stage call (entry points without a params argument derive their consts from it)
   bool haveParams = false;
   bool qposValid = false;    // qpos is the quantised copy of pstar[pcur] (written by the sort, delta-p and the slab refresh)
@@ -162,6 +195,7 @@ int ensure(pbf_ctx *ctx, DevBuf &b, size_t bytes, bool zero = false) {
   void *np = nullptr;
   const size_t want = bytes + bytes / 4 + 256;
   HIPCHK(ctx, hipMalloc(&np, want));
+  ctx->allocEpoch++;
   if (zero) HIPCHK(ctx, hipMemsetAsync(np, 0, want, ctx->stream));
   if (b.p) {
     // contents are never carried across a grow: callers refill
@@ -809,6 +843,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   else if (n == "fuse_diffuse") ctx->fuseDiffuse = value != 0;
   else if (n == "cell_diffuse") ctx->cellDiffuse = value != 0;
   else if (n == "pipeline") ctx->pipeline = int(value);
+  else if (n == "graph") ctx->graphMode = int(value);
   else if (n == "overlap_diffuse") ctx->overlapDiffuse = value != 0;
   else if (n == "coop") {
     if (value != 0 && value != 2 && value != 4 && value != 8) return fail(ctx, PBF_ERR_INVALID, "coop must be 0, 2, 4 or 8");
@@ -868,6 +903,7 @@ int pbf_create(const pbf_desc *desc, pbf_ctx **out) {
   if (const char *e = std::getenv("PBF_LIST_MAX")) ctx->listMax = uint32_t(std::atoi(e));
   if (const char *e = std::getenv("PBF_OVERLAP_DIFFUSE")) ctx->overlapDiffuse = std::atoi(e) != 0;
   if (const char *e = std::getenv("PBF_PIPELINE")) ctx->pipeline = std::atoi(e);
+  if (const char *e = std::getenv("PBF_GRAPH")) ctx->graphMode = std::atoi(e);
   if (const char *e = std::getenv("PBF_COOP")) {
     const int v = std::atoi(e);
     if (v == 0 || v == 2 || v == 4 || v == 8) ctx->coop = v;
@@ -908,6 +944,8 @@ void pbf_destroy(pbf_ctx *ctx) {
                    &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR, &ctx->colHist, &ctx->wireSend[0], &ctx->wireSend[1], &ctx->wireRecv[0], &ctx->wireRecv[1], &ctx->diffSum, &ctx->diffCnt};
   for (DevBuf *b : all)
     if (b->p) (void)hipFree(b->p);
+  for (auto &g : ctx->graphs)
+    if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
   if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
   if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
   if (ctx->sideStream) (void)hipStreamDestroy(ctx->sideStream);
@@ -1035,11 +1073,127 @@ int pbf_step(pbf_ctx *ctx, const pbf_params *p) {
   if (int rc = drop_ghosts(ctx)) return rc;
   return DISPATCH(ctx, step_impl, ctx, p);
 }
+namespace {
+
+DevBuf *role_buffers(pbf_ctx *ctx, DevBuf *out[15]) {
+  DevBuf *all[15] = {&ctx->pos4[0], &ctx->pos4[1], &ctx->vel4[0], &ctx->vel4[1], &ctx->col4[0], &ctx->col4[1],
+                     &ctx->id[0],   &ctx->id[1],   &ctx->type[0], &ctx->type[1], &ctx->key[0],  &ctx->key[1],
+                     &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2]};
+  for (int k = 0; k < 15; ++k) out[k] = all[k];
+  return nullptr;
+}
+StepState snapshot(pbf_ctx *ctx) {
+  StepState s;
+  std::memset(&s, 0, sizeof(s));  // (padding bytes take part in the comparison)
+  s.cur = ctx->cur, s.pcur = ctx->pcur;
+  s.flags = uint32_t(ctx->sorted) | uint32_t(ctx->counted) << 1 | uint32_t(ctx->nbrValid) << 2 | uint32_t(ctx->qposValid) << 3 |
+            uint32_t(ctx->hasObstacles) << 4;
+  s.tableN = ctx->tableN, s.countedTableN = ctx->countedTableN, s.gatherSeq = ctx->gatherSeq;
+  DevBuf *b[15];
+  role_buffers(ctx, b);
+  for (int k = 0; k < 3; ++k) s.extent[k] = ctx->extent[k], s.minExtent[k] = ctx->minExtent[k];
+  for (int k = 0; k < 15; ++k) s.bufs[k] = b[k]->p, s.caps[k] = b[k]->cap;
+  return s;
+}
+void restore(pbf_ctx *ctx, const StepState &s) {
+  ctx->cur = s.cur, ctx->pcur = s.pcur;
+  ctx->sorted = s.flags & 1u, ctx->counted = (s.flags >> 1) & 1u, ctx->nbrValid = (s.flags >> 2) & 1u;
+  ctx->qposValid = (s.flags >> 3) & 1u, ctx->hasObstacles = (s.flags >> 4) & 1u;
+  ctx->tableN = s.tableN, ctx->countedTableN = s.countedTableN, ctx->gatherSeq = s.gatherSeq;
+  DevBuf *b[15];
+  role_buffers(ctx, b);
+  for (int k = 0; k < 3; ++k) ctx->extent[k] = s.extent[k], ctx->minExtent[k] = s.minExtent[k];
+  for (int k = 0; k < 15; ++k) b[k]->p = s.bufs[k], b[k]->cap = s.caps[k];
+}
+GraphKey graph_key(pbf_ctx *ctx, const pbf_params *p) {
+  GraphKey k;
+  std::memset(&k, 0, sizeof(k));
+  k.before = snapshot(ctx);
+  double v[11] = {p->dt, p->scale, p->constant_force[0], p->constant_force[1], p->constant_force[2], p->min_bound[0],
+                  p->min_bound[1], p->min_bound[2], p->max_bound[0], p->max_bound[1], p->max_bound[2]};
+  std::memcpy(k.params, v, sizeof(v));
+  const uint64_t it = p->iteration;
+  const int32_t xv[2] = {p->xsph, p->vorticity};
+  std::memcpy(k.params + sizeof(v), &it, 8);
+  std::memcpy(k.params + sizeof(v) + 8, xv, 8);
+  k.n = ctx->n;
+  const int opt[10] = {ctx->gatherKind, ctx->splitBuild, ctx->coop, ctx->pipeline, int(ctx->cellDiffuse), int(ctx->overlapDiffuse),
+                       int(ctx->fuseDiffuse), int(ctx->reuseLists), int(ctx->listMax), int(ctx->tileCap)};
+  std::memcpy(k.options, opt, sizeof(opt));
+  return k;
+}
+
+// One step of pbf_steps: replayed from a captured graph when this exact step (same buffer roles, same parameters) has been
+// seen before, captured the first time it comes by, eager whenever capturing is not possible.
+int step_maybe_graphed(pbf_ctx *ctx, const pbf_params *p) {
+  const bool timing = (ctx->desc.flags & PBF_FLAG_STAGE_TIMING) != 0 && ctx->timingMask != 0;
+  if (ctx->graphMode <= 0 || timing || p->n_wells > 0 || ctx->n == 0 || ctx->slabConfigured)
+    return DISPATCH(ctx, step_impl, ctx, p);
+  const GraphKey key = graph_key(ctx, p);
+  auto it = ctx->graphs.find(key);
+  if (it != ctx->graphs.end()) {
+    HIPCHK(ctx, hipGraphLaunch(it->second.exec, ctx->stream));
+    restore(ctx, it->second.after);
+    ctx->graphMisses = 0;
+    ctx->graphReplays++;
+    return PBF_OK;
+  }
+  if (ctx->graphs.size() >= 32 || ctx->graphMisses >= 8) {  // the steps never repeat (a box that moves every frame)
+    ctx->graphMode = 0;
+    return DISPATCH(ctx, step_impl, ctx, p);
+  }
+  // capture only a step that allocates nothing: run it eagerly once more if the last one still grew a buffer
+  const uint64_t epoch = ctx->allocEpoch;
+  if (ctx->graphCaptures == 0 && ctx->graphReplays == 0 && ctx->graphMisses == 0) {
+    ctx->graphMisses = 1;  // the very first step after an upload allocates (scratch, side stream): eager
+    return DISPATCH(ctx, step_impl, ctx, p);
+  }
+  hipGraph_t graph = nullptr;
+  if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->graphMode = 0;
+    return DISPATCH(ctx, step_impl, ctx, p);
+  }
+  const int rc = DISPATCH(ctx, step_impl, ctx, p);
+  const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+  if (rc != PBF_OK || e != hipSuccess || !graph || ctx->allocEpoch != epoch) {
+    // could not be captured (an allocation, a call that is illegal while capturing): nothing ran — redo it eagerly
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    ctx->graphMode = 0;
+    restore(ctx, key.before);
+    ctx->diffusePending = false;
+    return DISPATCH(ctx, step_impl, ctx, p);
+  }
+  GraphEntry entry;
+  const hipError_t ei = hipGraphInstantiate(&entry.exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->graphMode = 0;
+    restore(ctx, key.before);
+    ctx->diffusePending = false;
+    return DISPATCH(ctx, step_impl, ctx, p);
+  }
+  entry.after = snapshot(ctx);
+  ctx->graphs.emplace(key, entry);
+  ctx->graphCaptures++, ctx->graphMisses++;
+  HIPCHK(ctx, hipGraphLaunch(entry.exec, ctx->stream));  // the capture recorded the step; this runs it
+  return PBF_OK;
+}
+
+}  // namespace
+
 int pbf_steps(pbf_ctx *ctx, const pbf_params *p, uint32_t count) {
   if (int rc = check(ctx, p, false)) return rc;
   if (int rc = drop_ghosts(ctx)) return rc;
   for (uint32_t i = 0; i < count; ++i)
-    if (int rc = DISPATCH(ctx, step_impl, ctx, p)) return rc;
+    if (int rc = step_maybe_graphed(ctx, p)) return rc;
+  return PBF_OK;
+}
+int pbf_graph_stats(const pbf_ctx *ctx, uint64_t out[3]) {
+  if (!ctx || !out) return PBF_ERR_INVALID;
+  out[0] = ctx->graphCaptures, out[1] = ctx->graphReplays, out[2] = uint64_t(ctx->graphMode > 0);
   return PBF_OK;
 }
 int pbf_sync(pbf_ctx *ctx) {

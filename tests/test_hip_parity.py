@@ -624,3 +624,41 @@ def test_ranged_sqrt_and_divide_are_the_ieee_ones(pkg):
     bad = np.zeros(2, np.uint64)
     s._chk(s.L.pbf_selftest_math(s.ctx, bad.ctypes.data_as(C.c_void_p)), "pbf_selftest_math")
     assert bad[0] == 0 and bad[1] == 0, bad
+
+
+@pytest.mark.parametrize("fp64", [False, True])
+def test_graph_replay_bit_exact(pkg, oracle, fp64):
+    """pbf_steps replays each distinct step as a captured hipGraph (option graph, default on): the buffer roles rotate
+    with a short period, so after a few captures every step is a replay.  Same launches, same arguments => the same
+    bits as the eager loop and as the oracle; a moving box (parameters change every frame) falls back to eager."""
+    sc, side = get_scene(pkg, "dam8192", fp64)
+    p, q = params_pair(pkg, oracle, side=side)
+    a = pkg.Solver(h=0.1, fp64=fp64)
+    a.upload(**sc)
+    for _ in range(6):
+        a.steps(p, 4)          # 24 frames, several calls
+    captured, replayed, on = a.graph_stats()
+    assert on and 1 <= captured <= 12 and replayed >= 24 - 1 - captured, (captured, replayed, on)
+    b = pkg.Solver(h=0.1, fp64=fp64)
+    b.set_option("graph", 0)
+    b.upload(**sc)
+    b.steps(p, 24)
+    assert b.graph_stats()[:2] == (0, 0)
+    assert_state_equal(a.download(), b.download(), "graph vs eager")
+    o = oracle.Oracle(fp64, device_pow=True)
+    o.set_particles(**sc)
+    for _ in range(24):
+        o.step(q)
+    assert_state_equal(a.download(), o.get_particles(), "graph vs oracle")
+    # a box that moves every frame never repeats a step: graphs switch themselves off, results stay right
+    c = pkg.Solver(h=0.1, fp64=fp64)
+    c.upload(**sc)
+    d = pkg.Solver(h=0.1, fp64=fp64)
+    d.set_option("graph", 0)
+    d.upload(**sc)
+    for frame in range(14):
+        pm = pkg.apply_motion(p, frame, fp64)
+        c.steps(pm, 1)
+        d.steps(pm, 1)
+    assert c.graph_stats()[2] is False
+    assert_state_equal(c.download(), d.download(), "moving box")
