@@ -123,9 +123,12 @@ struct pbf_ctx {
   void *regPtr = nullptr;
   size_t regBytes = 0;
   size_t stagedBytes = 0;  // bytes of `staging` that hold a defined AoS image (padding bytes of a download come from it)
-  // option "graph" (default on): pbf_steps replays each distinct step as a captured hipGraph (one graph launch instead
-  // of ~25 kernel launches); stage timing, wells, growing buffers or a box that moves every frame fall back to eager
-  int graphMode = 1;
+  // option "graph" (default OFF): pbf_steps replays each distinct step as a captured hipGraph (one graph launch instead
+  // of ~25 kernel launches); stage timing, wells, growing buffers or a box that moves every frame fall back to eager.
+  // Measured on MI355X / ROCm 7 (tools/graph_ab.sh): replay is SLOWER than the eager launches — 0.294 vs 0.269 ms/step
+  // at 16 K particles, 0.512 vs 0.479 at 256 K, 1.724 vs 1.709 at 1 M: the step is never host-launch bound (the host
+  // enqueues a step in ~90 us) and a graph does not shorten the dependent-kernel boundary.
+  int graphMode = 0;
   std::map<GraphKey, GraphEntry> graphs;
   uint64_t allocEpoch = 0;     // bumped by every hipMalloc of ensure(): a step that allocated is not captured
   uint32_t graphMisses = 0;    // captures without a replay in between: a scene that never repeats turns graphs off

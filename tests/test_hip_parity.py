@@ -628,12 +628,14 @@ def test_ranged_sqrt_and_divide_are_the_ieee_ones(pkg):
 
 @pytest.mark.parametrize("fp64", [False, True])
 def test_graph_replay_bit_exact(pkg, oracle, fp64):
-    """pbf_steps replays each distinct step as a captured hipGraph (option graph, default on): the buffer roles rotate
+    """pbf_steps can replay each distinct step as a captured hipGraph (option graph; off by default: measured slower than
+    eager launches): the buffer roles rotate
     with a short period, so after a few captures every step is a replay.  Same launches, same arguments => the same
     bits as the eager loop and as the oracle; a moving box (parameters change every frame) falls back to eager."""
     sc, side = get_scene(pkg, "dam8192", fp64)
     p, q = params_pair(pkg, oracle, side=side)
     a = pkg.Solver(h=0.1, fp64=fp64)
+    a.set_option("graph", 1)
     a.upload(**sc)
     for _ in range(6):
         a.steps(p, 4)          # 24 frames, several calls
@@ -652,6 +654,7 @@ def test_graph_replay_bit_exact(pkg, oracle, fp64):
     assert_state_equal(a.download(), o.get_particles(), "graph vs oracle")
     # a box that moves every frame never repeats a step: graphs switch themselves off, results stay right
     c = pkg.Solver(h=0.1, fp64=fp64)
+    c.set_option("graph", 1)
     c.upload(**sc)
     d = pkg.Solver(h=0.1, fp64=fp64)
     d.set_option("graph", 0)
