@@ -472,6 +472,9 @@ def main():
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if drv is not None:
+        solver.sync()
+        drv.close()  # ncclCommDestroy before the process group goes away
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

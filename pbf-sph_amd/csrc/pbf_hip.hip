@@ -1636,7 +1636,7 @@ template <typename N> int slab_step_impl(pbf_ctx *ctx, const pbf_params *p) {
   ctx->sentL = own[0], ctx->sentR = own[1];
   if (int rc = slab_add_ghosts<N>(ctx, rL, got[0], rR, got[1])) return rc;
   if (int rc = stage_sort<N>(ctx, p)) return rc;
-  if (int rc = stage_diffuse<N>(ctx, p)) return rc;
+  if (int rc = stage_diffuse<N>(ctx, p, /*overlap=*/p->iteration > 0)) return rc;  // beside the iterations, like pbf_step
   // ---- K x { lambda, delta-p }, each followed by the owners refreshing their copies' {pStar, lambda} ------
   const size_t fb = sizeof(vec4<N>);
   auto refresh = [&]() -> int {
@@ -1651,6 +1651,7 @@ template <typename N> int slab_step_impl(pbf_ctx *ctx, const pbf_params *p) {
     if (int rc = refresh()) return rc;
   }
   if (int rc = stage_finalise<N>(ctx, p)) return rc;
+  if (int rc = join_diffuse(ctx)) return rc;
   // The copies stay where they are: the next step's migration select drops them on its way (one whole-array
   // compaction per step saved); whoever looks at the arrays from outside calls drop_ghosts() first.
   ctx->ghostsPending = true;
