@@ -218,7 +218,8 @@ int pbf_slab_column_histogram(pbf_ctx *ctx, uint32_t out[1024]);
  * pbf_slab_attach hands the communicator, the cuts (nranks + 1 column boundaries, identical on every rank) and the
  * wire capacities to the ctx; pbf_slab_step then runs ONE step including every exchange:
  *   predict -> [migrants] -> [ghost copies] -> sort -> diffuse -> K x { lambda -> [field] -> delta -> [field] }
- *   -> finalise                ([..] = one exchange round: 2 + 2K rounds per step)
+ *   -> finalise [-> xsph / vorticity extras with 3 more field rounds when requested]
+ *                              ([..] = one exchange round: 2 + 2K rounds per step)
  * The two assembly rounds carry their record counts in the header of a fixed-size first message {header | first
  * cap_* records} (no count round trip); the host reads those counts once per assembly round (2 small synchronising
  * read-backs per step), the 2K field rounds need none.  Only when a side holds more records than the first message

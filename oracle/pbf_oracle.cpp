@@ -397,56 +397,73 @@ template <typename N> struct Oracle final : pbf_oracle {
   // Opt-in extras, ABSENT from the reference (only the constants survive, sph_constants.h:13-14;
   // SURVEY finding 3).  Macklin & Mueller 2013 eq. 15-17 on the post-solve velocity; Jacobi only.
   // parity unpinned: there is no reference implementation to compare with.
-  void extras(const pbf_oracle_params &c, std::vector<V3<N>> &v) {
-    if (!c.xsph && !c.vorticity) return;
+  // The three sub-stages are also entry points of their own (pbf_oracle_vorticity / _vorticity_force / _xsph): the slab
+  // twin (tests/slab_engines.py) refreshes the ghost copies' velocity / vorticity between them.
+  std::vector<V3<N>> omega;  // vorticity of the last vorticity_omega()
+  void vorticity_omega(const pbf_oracle_params &c) {
+    const size_t cnt = n();
+    const N h = N(c.h);
+    const N SpikyKernelFactor = spikyKernelFactor(h);
+    const std::vector<V3<N>> &v = vel;
+    omega.assign(cnt, V3<N>{N(0), N(0), N(0)});
+    foreach_1d(c.threads, cnt, [&](size_t a) {
+      if (type[a] != 0) return;
+      V3<N> w{N(0), N(0), N(0)};
+      foreach_grid(zIndex[a], [&](size_t b) {
+        const N r = distance(pStar[a], pStar[b]);
+        const V3<N> g = spikyKernelGradient(pStar[a], pStar[b], r, h, SpikyKernelFactor);
+        const V3<N> vij = v[b] - v[a];
+        w = w + V3<N>{vij.y * g.z - vij.z * g.y, vij.z * g.x - vij.x * g.z, vij.x * g.y - vij.y * g.x};
+      });
+      omega[a] = w;
+    });
+  }
+  void vorticity_force(const pbf_oracle_params &c) {
     const size_t cnt = n();
     const N h = N(c.h), dt = N(c.dt);
-    const N Poly6Factor = poly6Factor(h);
     const N SpikyKernelFactor = spikyKernelFactor(h);
-    std::vector<V3<N>> omega(cnt, V3<N>{N(0), N(0), N(0)});
-    std::vector<V3<N>> vnew = v;
+    if (omega.size() != cnt) omega.assign(cnt, V3<N>{N(0), N(0), N(0)});
+    std::vector<V3<N>> vnew = vel;
+    foreach_1d(c.threads, cnt, [&](size_t a) {
+      if (type[a] != 0) return;
+      V3<N> eta{N(0), N(0), N(0)};
+      foreach_grid(zIndex[a], [&](size_t b) {
+        const N r = distance(pStar[a], pStar[b]);
+        const V3<N> g = spikyKernelGradient(pStar[a], pStar[b], r, h, SpikyKernelFactor);
+        eta = eta + g * std::sqrt(dot(omega[b], omega[b]));
+      });
+      const N len = std::sqrt(dot(eta, eta));
+      if (len > N(EPSILON)) {
+        const V3<N> nn = eta * (N(1) / len);
+        const V3<N> w = omega[a];
+        const V3<N> f{nn.y * w.z - nn.z * w.y, nn.z * w.x - nn.x * w.z, nn.x * w.y - nn.y * w.x};
+        vnew[a] = vnew[a] + f * (N(VORTICITY_EPSILON) * dt);
+      }
+    });
+    vel.swap(vnew);
+  }
+  void xsph(const pbf_oracle_params &c) {
+    const size_t cnt = n();
+    const N h = N(c.h);
+    const N Poly6Factor = poly6Factor(h);
+    const std::vector<V3<N>> base = vel;
+    foreach_1d(c.threads, cnt, [&](size_t a) {
+      if (type[a] != 0) return;
+      V3<N> acc{N(0), N(0), N(0)};
+      foreach_grid(zIndex[a], [&](size_t b) {
+        const N r = distance(pStar[a], pStar[b]);
+        acc = acc + (base[b] - base[a]) * poly6Kernel(r, Poly6Factor, h);
+      });
+      vel[a] = base[a] + acc * N(C_XSPH);
+    });
+  }
+  void extras(const pbf_oracle_params &c, std::vector<V3<N>> &v) {
+    (void)v;  // (always `vel`)
     if (c.vorticity) {
-      foreach_1d(c.threads, cnt, [&](size_t a) {
-        if (type[a] != 0) return;
-        V3<N> w{N(0), N(0), N(0)};
-        foreach_grid(zIndex[a], [&](size_t b) {
-          const N r = distance(pStar[a], pStar[b]);
-          const V3<N> g = spikyKernelGradient(pStar[a], pStar[b], r, h, SpikyKernelFactor);
-          const V3<N> vij = v[b] - v[a];
-          w = w + V3<N>{vij.y * g.z - vij.z * g.y, vij.z * g.x - vij.x * g.z, vij.x * g.y - vij.y * g.x};
-        });
-        omega[a] = w;
-      });
-      foreach_1d(c.threads, cnt, [&](size_t a) {
-        if (type[a] != 0) return;
-        V3<N> eta{N(0), N(0), N(0)};
-        foreach_grid(zIndex[a], [&](size_t b) {
-          const N r = distance(pStar[a], pStar[b]);
-          const V3<N> g = spikyKernelGradient(pStar[a], pStar[b], r, h, SpikyKernelFactor);
-          eta = eta + g * std::sqrt(dot(omega[b], omega[b]));
-        });
-        const N len = std::sqrt(dot(eta, eta));
-        if (len > N(EPSILON)) {
-          const V3<N> nn = eta * (N(1) / len);
-          const V3<N> w = omega[a];
-          const V3<N> f{nn.y * w.z - nn.z * w.y, nn.z * w.x - nn.x * w.z, nn.x * w.y - nn.y * w.x};
-          vnew[a] = vnew[a] + f * (N(VORTICITY_EPSILON) * dt);
-        }
-      });
+      vorticity_omega(c);
+      vorticity_force(c);
     }
-    if (c.xsph) {
-      std::vector<V3<N>> base = vnew;
-      foreach_1d(c.threads, cnt, [&](size_t a) {
-        if (type[a] != 0) return;
-        V3<N> acc{N(0), N(0), N(0)};
-        foreach_grid(zIndex[a], [&](size_t b) {
-          const N r = distance(pStar[a], pStar[b]);
-          acc = acc + (base[b] - base[a]) * poly6Kernel(r, Poly6Factor, h);
-        });
-        vnew[a] = base[a] + acc * N(C_XSPH);
-      });
-    }
-    v.swap(vnew);
+    if (c.xsph) xsph(c);
   }
 
 
@@ -933,6 +950,36 @@ size_t pbf_oracle_query(const pbf_oracle *o, const pbf_oracle_params *p, const d
         ++k;
       }
     return k;
+  });
+}
+
+// ---- the opt-in extras as stages of their own (the slab twin exchanges ghost data between them) ------------
+int pbf_oracle_vorticity(pbf_oracle *o, const pbf_oracle_params *p) {
+  return dispatch(o, [&](auto &s) { s.vorticity_omega(*p); return 0; });
+}
+int pbf_oracle_vorticity_force(pbf_oracle *o, const pbf_oracle_params *p) {
+  return dispatch(o, [&](auto &s) { s.vorticity_force(*p); return 0; });
+}
+int pbf_oracle_xsph(pbf_oracle *o, const pbf_oracle_params *p) {
+  return dispatch(o, [&](auto &s) { s.xsph(*p); return 0; });
+}
+// which: 0 = velocity, 1 = vorticity; n x 3 values of N
+int pbf_oracle_get_vec(const pbf_oracle *o, int which, void *out) {
+  return dispatch(o, [&](const auto &s) {
+    using N = std::decay_t<decltype(s.mass[0])>;
+    const auto &v = which ? s.omega : s.vel;
+    if (v.size() != s.n()) return 1;
+    std::memcpy(out, v.data(), s.n() * 3 * sizeof(N));
+    return 0;
+  });
+}
+int pbf_oracle_set_vec(pbf_oracle *o, int which, const void *in) {
+  return dispatch(o, [&](auto &s) {
+    using N = std::decay_t<decltype(s.mass[0])>;
+    auto &v = which ? s.omega : s.vel;
+    v.resize(s.n());
+    std::memcpy(v.data(), in, s.n() * 3 * sizeof(N));
+    return 0;
   });
 }
 

@@ -141,6 +141,15 @@ int pbf_oracle_scene_emit(pbf_oracle *, double h, double scale, size_t n_sources
 int pbf_oracle_scene_drain(pbf_oracle *, size_t n_drains, const double *drains);
 size_t pbf_oracle_query(const pbf_oracle *, const pbf_oracle_params *, const double point[3], uint64_t *out, size_t cap);
 
+/* The opt-in extras (absent from the reference) as stages of their own, run after pbf_oracle_finalise with xsph =
+ * vorticity = 0: vorticity -> vorticity_force -> xsph is what finalise does itself when the flags are set.  The slab
+ * twin refreshes the ghost copies' velocity (which = 0) / vorticity (which = 1) between them. */
+int pbf_oracle_vorticity(pbf_oracle *, const pbf_oracle_params *);
+int pbf_oracle_vorticity_force(pbf_oracle *, const pbf_oracle_params *);
+int pbf_oracle_xsph(pbf_oracle *, const pbf_oracle_params *);
+int pbf_oracle_get_vec(const pbf_oracle *, int which, void *out);
+int pbf_oracle_set_vec(pbf_oracle *, int which, const void *in);
+
 #ifdef __cplusplus
 }
 #endif

@@ -717,7 +717,7 @@ template <typename N, bool FAST> int extras_impl(pbf_ctx *ctx, const pbf_params 
   return PBF_OK;
 }
 template <typename N> int extras(pbf_ctx *ctx, const pbf_params *p, const StepConsts<N> &c) {
-  if (ctx->slabActive) return fail(ctx, PBF_ERR_INVALID, "vorticity / xsph are not available in slab mode yet");
+  if (ctx->slabActive) return PBF_OK;  // slab mode: pbf_slab_step runs them itself, with the ghost refreshes in between
   return ctx->fast ? extras_impl<N, true>(ctx, p, c) : extras_impl<N, false>(ctx, p, c);
 }
 
@@ -1398,18 +1398,19 @@ template <typename N> int slab_add_ghosts(pbf_ctx *ctx, const void *rL, uint32_t
   return PBF_OK;
 }
 
-template <typename N> int slab_pack(pbf_ctx *ctx, void *sL, void *sR) {
+template <typename N> int slab_pack(pbf_ctx *ctx, void *sL, void *sR, const void *field = nullptr) {
   const uint32_t m = ctx->sentL + ctx->sentR;
+  const vec4<N> *src = field ? static_cast<const vec4<N> *>(field) : ctx->pstar[ctx->pcur].as<const vec4<N>>();
   if (m)
     hipLaunchKernelGGL((k_pack_field<N>), grid_for(m), dim3(BLOCK), 0, ctx->stream, ctx->sentL, ctx->sentR,
                        ctx->ghostSrcL.as<const uint32_t>(), ctx->ghostSrcR.as<const uint32_t>(),
-                       ctx->slotOf.as<const uint32_t>(), ctx->pstar[ctx->pcur].as<const vec4<N>>(),
+                       ctx->slotOf.as<const uint32_t>(), src,
                        static_cast<vec4<N> *>(sL), static_cast<vec4<N> *>(sR));
   LAUNCH_CHECK(ctx);
   return PBF_OK;
 }
 
-template <typename N> int slab_unpack(pbf_ctx *ctx, const void *rL, const void *rR) {
+template <typename N> int slab_unpack(pbf_ctx *ctx, const void *rL, const void *rR, void *field = nullptr) {
   const uint32_t m = ctx->gotL + ctx->gotR;
   StepConsts<N> c;
   if (!ctx->haveParams) return fail(ctx, PBF_ERR_STATE, "pbf_slab_unpack before any stage");
@@ -1417,7 +1418,8 @@ template <typename N> int slab_unpack(pbf_ctx *ctx, const void *rL, const void *
   if (m)
     hipLaunchKernelGGL((k_unpack_field<N>), grid_for(m), dim3(BLOCK), 0, ctx->stream, c, ctx->nOwned, ctx->gotL, ctx->gotR,
                        static_cast<const vec4<N> *>(rL), static_cast<const vec4<N> *>(rR),
-                       ctx->slotOf.as<const uint32_t>(), ctx->pstar[ctx->pcur].as<vec4<N>>(), ctx->qpos.as<uint2>());
+                       ctx->slotOf.as<const uint32_t>(), field ? static_cast<vec4<N> *>(field) : ctx->pstar[ctx->pcur].as<vec4<N>>(),
+                       field ? nullptr : ctx->qpos.as<uint2>());
   LAUNCH_CHECK(ctx);
   return PBF_OK;
 }
@@ -1621,6 +1623,41 @@ int assembly_round(pbf_ctx *ctx, uint32_t chunk, size_t recBytes, int idxL, int 
   return PBF_OK;
 }
 
+// The opt-in extras in slab mode: the same three gather ops as extras_impl, with the owners refreshing their copies'
+// velocity / vorticity before each op that reads them (the copies' velocities are not part of the ghost records).
+template <typename N, bool FAST> int slab_extras_impl(pbf_ctx *ctx, const pbf_params *p) {
+  StepConsts<N> c;
+  if (int rc = make_consts<N>(ctx, p, c)) return rc;
+  const uint8_t *type = ctx->type[ctx->cur].as<const uint8_t>();
+  const vec4<N> *ps = ctx->pstar[ctx->cur].as<const vec4<N>>();
+  const size_t fb = sizeof(vec4<N>);
+  auto refresh = [&](void *field) -> int {
+    if (int rc = slab_pack<N>(ctx, ctx->wireSend[0].p, ctx->wireSend[1].p, field)) return rc;
+    if (int rc = exchange(ctx, ctx->sentL * fb, ctx->sentR * fb, ctx->gotL * fb, ctx->gotR * fb)) return rc;
+    return slab_unpack<N>(ctx, ctx->wireRecv[0].p, ctx->wireRecv[1].p, field);
+  };
+  auto vel = [&](int k) { return ctx->vel4[k].as<vec4<N>>(); };
+  int s = ctx->cur, o = 1 - s;
+  if (int rc = refresh(vel(s))) return rc;
+  if (p->vorticity) {
+    vec4<N> *omega = ctx->pstar[2].as<vec4<N>>();
+    typename VorticityOp<N, FAST>::Args a1{ps, vel(s), omega, type};
+    if (int rc = launch_gather<N, VorticityOp<N, FAST>>(ctx, c, a1)) return rc;
+    if (int rc = refresh(omega)) return rc;
+    typename VorticityForceOp<N, FAST>::Args a2{ps, omega, vel(s), vel(o), type};
+    if (int rc = launch_gather<N, VorticityForceOp<N, FAST>>(ctx, c, a2)) return rc;
+    std::swap(ctx->vel4[s], ctx->vel4[o]);
+    if (p->xsph)
+      if (int rc = refresh(vel(s))) return rc;
+  }
+  if (p->xsph) {
+    typename XsphOp<N, FAST>::Args a3{ps, vel(s), vel(o), type};
+    if (int rc = launch_gather<N, XsphOp<N, FAST>>(ctx, c, a3)) return rc;
+    std::swap(ctx->vel4[s], ctx->vel4[o]);
+  }
+  return PBF_OK;
+}
+
 template <typename N> int slab_step_impl(pbf_ctx *ctx, const pbf_params *p) {
   if (int rc = stage_predict<N>(ctx, p)) return rc;
   const uint8_t *rL = ctx->wireRecv[0].as<const uint8_t>() + WIRE_HDR, *rR = ctx->wireRecv[1].as<const uint8_t>() + WIRE_HDR;
@@ -1651,6 +1688,8 @@ template <typename N> int slab_step_impl(pbf_ctx *ctx, const pbf_params *p) {
     if (int rc = refresh()) return rc;
   }
   if (int rc = stage_finalise<N>(ctx, p)) return rc;
+  if (p->vorticity || p->xsph)
+    if (int rc = ctx->fast ? slab_extras_impl<N, true>(ctx, p) : slab_extras_impl<N, false>(ctx, p)) return rc;
   if (int rc = join_diffuse(ctx)) return rc;
   // The copies stay where they are: the next step's migration select drops them on its way (one whole-array
   // compaction per step saved); whoever looks at the arrays from outside calls drop_ghosts() first.
@@ -1775,7 +1814,6 @@ int pbf_slab_step(pbf_ctx *ctx, const pbf_params *p) { return pbf_slab_steps(ctx
 int pbf_slab_steps(pbf_ctx *ctx, const pbf_params *p, uint32_t count) {
   if (int rc = check(ctx, p, false)) return rc;
   if (!ctx->comm) return fail(ctx, PBF_ERR_STATE, "pbf_slab_step needs pbf_slab_attach first");
-  if (p->vorticity || p->xsph) return fail(ctx, PBF_ERR_INVALID, "vorticity / xsph are not available in slab mode yet");
   for (uint32_t i = 0; i < count; ++i)
     if (int rc = DISPATCH(ctx, slab_step_impl, ctx, p)) return rc;
   return PBF_OK;

@@ -244,8 +244,10 @@ __global__ __launch_bounds__(BLOCK) void k_unpack_field(StepConsts<N> c, uint32_
   const vec4<N> v = j < nL ? inL[j] : inR[j - nL];
   const uint32_t d = slotOf[ghostAt + j];
   pstar[d] = v;
-  bool usable;
-  qpos[d] = quantise_position<N>(c, v, &usable);  // keeps the list build's quantised copy in step with pStar
+  if (qpos) {  // (NULL when the field is not pStar: the extras' velocity / vorticity refresh)
+    bool usable;
+    qpos[d] = quantise_position<N>(c, v, &usable);  // keeps the list build's quantised copy in step with pStar
+  }
 }
 
 }  // namespace pbf

@@ -404,7 +404,24 @@ class SlabSolver:
                 e.pack(self.send[0], self.send[1])
                 self._exchange((self.sent[0] * fb, self.sent[1] * fb), (self.got[0] * fb, self.got[1] * fb))
                 e.unpack(self.recv[0], self.recv[1])
-        e.stage("finalise", p)
+        e.stage("finalise", p)  # (engines run the core finalise here: the extras follow, with their refreshes)
+        if p.xsph or p.vorticity:
+            vb = 3 * (8 if getattr(e, "fdt", np.float32) == np.float64 else 4)
+
+            def refresh(which):  # owners -> copies: velocity (0) / vorticity (1)
+                e.pack_vec(which, self.send[0], self.send[1])
+                self._exchange((self.sent[0] * vb, self.sent[1] * vb), (self.got[0] * vb, self.got[1] * vb))
+                e.unpack_vec(which, self.recv[0], self.recv[1])
+
+            refresh(0)
+            if p.vorticity:
+                e.extras_stage("vorticity", p)
+                refresh(1)
+                e.extras_stage("vorticity_force", p)
+                if p.xsph:
+                    refresh(0)
+            if p.xsph:
+                e.extras_stage("xsph", p)
         e.finish()
 
     def steps(self, p, count):

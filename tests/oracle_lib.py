@@ -126,6 +126,12 @@ def _bind(L):
                                                   C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.pbf_oracle_get_lattice.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pbf_oracle_get_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for name in ("vorticity", "vorticity_force", "xsph"):
+        f = getattr(L, "pbf_oracle_" + name)
+        f.argtypes = [C.c_void_p, C.POINTER(OracleParams)]
+        f.restype = C.c_int
+    L.pbf_oracle_get_vec.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.pbf_oracle_set_vec.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.pbf_oracle_scene_emit.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_size_t, C.c_void_p, C.c_void_p]
     L.pbf_oracle_scene_drain.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     L.pbf_oracle_query.restype = C.c_size_t
@@ -303,6 +309,25 @@ class Oracle:
         pn, cc = np.empty((nn, 4), self.dtype), np.empty((nn, 4), self.dtype)
         self.L.pbf_oracle_get_lattice(self.h, _vp(smp), _vp(pn), _vp(cc))
         return dict(vs=vs, ns=ns, cs=cs, sample=smp, pn=pn, c=cc)
+
+    # -- the opt-in extras as stages of their own (slab twin) --
+    def vorticity(self, p):
+        return self._stage("vorticity", p)
+
+    def vorticity_force(self, p):
+        return self._stage("vorticity_force", p)
+
+    def xsph(self, p):
+        return self._stage("xsph", p)
+
+    def get_vec(self, which):
+        a = np.empty((self.n, 3), self.dtype)
+        assert self.L.pbf_oracle_get_vec(self.h, which, _vp(a)) == 0
+        return a
+
+    def set_vec(self, which, a):
+        a = np.ascontiguousarray(a, self.dtype).reshape(self.n, 3)
+        self.L.pbf_oracle_set_vec(self.h, which, _vp(a))
 
     # -- scene dynamics on the host side of advance() (ompsph.hpp:91-126, 167-186) --
     def emit(self, sources, h=0.1, scale=500.0):

@@ -206,6 +206,25 @@ class OracleEngine:
             at += n
         self.o.set_scratch(None, ps, la)
 
+    # -- opt-in extras in slab mode: the owners refresh their copies' velocity / vorticity between the sub-stages --
+    def extras_stage(self, name, p):
+        getattr(self.o, name)(self.q)
+
+    def pack_vec(self, which, send_l, send_r):
+        v = self.o.get_vec(which)
+        for idx, buf in zip(self.src, (send_l, send_r)):
+            self._write(buf, np.ascontiguousarray(v[self.slot_of[idx]]))
+
+    def unpack_vec(self, which, recv_l, recv_r):
+        v = self.o.get_vec(which)
+        at = self.n_owned_
+        dt3 = np.dtype((self.fdt, 3))
+        for buf, n in ((recv_l, self.got[0]), (recv_r, self.got[1])):
+            if n:
+                v[self.slot_of[at:at + n]] = self._read(buf, dt3, n)
+            at += n
+        self.o.set_vec(which, v)
+
     def finish(self):
         st = self._state()
         keep = np.flatnonzero((st["type"] & GHOST) == 0)

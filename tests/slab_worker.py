@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--fp64", action="store_true")
     ap.add_argument("--rebalance", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0, help="records in the first message of an assembly round (hipc)")
+    ap.add_argument("--xsph", type=int, default=0)
+    ap.add_argument("--vorticity", type=int, default=0)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -40,6 +42,7 @@ def main():
     else:
         sc, side = pkg.scene_dambreak(int(a.scene[3:]), a.fp64)
     p = pkg.default_params(a.iteration, side)
+    p.xsph, p.vorticity = a.xsph, a.vorticity
     if a.cuts == "even":
         cuts = slab.even_cuts(world, side)
     elif a.cuts.startswith("x:"):  # explicit world-space cut positions

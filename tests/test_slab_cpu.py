@@ -124,3 +124,32 @@ def test_slabs_rebalance_cpu(oracle, pkg, tmp_path, scene, cuts):
     wo = np.argsort(w["id"], kind="stable")
     d = np.linalg.norm(got["pos"].astype(np.float64) - w["pos"][wo], axis=1)
     assert np.percentile(d, 99) <= 0.5 and d.mean() <= 0.05, (d.max(), d.mean())
+
+
+@pytest.mark.parametrize("xsph,vort", [(1, 1), (1, 0), (0, 1)])
+def test_slabs_with_xsph_and_vorticity_cpu(oracle, pkg, tmp_path, xsph, vort):
+    """The opt-in extras in slab mode: the owners refresh their copies' velocity / vorticity before each op that reads
+    them; the union equals the single-rank oracle (which runs the three ops back to back) to summation-order noise."""
+    steps = 4
+    parts = launch(2, str(tmp_path), "--engine", "oracle", "--scene", "cubes2048", "--steps", str(steps), "--cuts", "x:210",
+                   "--xsph", str(xsph), "--vorticity", str(vort))
+    got = merged(parts)
+    sc = pkg.scene_cubes(2048)
+    assert np.array_equal(got["id"], np.sort(sc["id"]))
+    o = oracle.Oracle(False, device_pow=True)
+    o.set_particles(**sc)
+    q = oracle.make_params(mode=oracle.JACOBI, sort=oracle.SORT_STABLE, threads=2, xsph=xsph, vorticity=vort)
+    plain = oracle.Oracle(False, device_pow=True)
+    plain.set_particles(**sc)
+    q0 = oracle.make_params(mode=oracle.JACOBI, sort=oracle.SORT_STABLE, threads=2)
+    for _ in range(steps):
+        o.step(q)
+        plain.step(q0)
+    w = o.get_particles()
+    wo = np.argsort(w["id"], kind="stable")
+    dv = np.abs(got["vel"].astype(np.float64) - w["vel"][wo]).max()
+    d = np.linalg.norm(got["pos"].astype(np.float64) - w["pos"][wo], axis=1)
+    assert d.max() <= 2e-2 and d.mean() <= 1e-4 and dv <= 1e-3, (d.max(), d.mean(), dv)
+    # ... and the extras really act (the comparison above is not vacuous)
+    wp = plain.get_particles()
+    assert np.abs(w["vel"][wo] - wp["vel"][np.argsort(wp["id"], kind="stable")]).max() > 1e-6

@@ -52,6 +52,20 @@ def test_hip_slabs_small_first_message(pkg, tmp_path):
     assert int(hip[1]["exchanges"]) > 4 * (2 + 2 * 4)   # the remainder rounds happened
 
 
+@pytest.mark.parametrize("fp64", [False, True])
+def test_hip_slabs_xsph_vorticity_bit_exact(pkg, tmp_path, fp64):
+    """XSPH + vorticity confinement in slab mode (pbf_slab_step: three more field refreshes — velocity, vorticity,
+    velocity — around the three gather ops): the same bits as the CPU twin, 3 ranks, and 2 + 2K + 3 rounds per step."""
+    args = ("--scene", "cubes2048", "--steps", "4", "--cuts", "x:210,700", "--xsph", "1", "--vorticity", "1") + \
+        (("--fp64",) if fp64 else ())
+    hip = launch(3, str(tmp_path / "hip"), "--engine", "hipc", *args)
+    ora = launch(3, str(tmp_path / "ora"), "--engine", "oracle", *args)
+    for r in range(3):
+        for k in ("id", "pos", "vel", "colour", "type"):
+            assert np.array_equal(hip[r][k], ora[r][k]), (r, k)
+    assert int(hip[1]["exchanges"]) == 4 * (2 + 2 * 4 + 3)
+
+
 def test_hip_slabs_fp64_bit_exact(pkg, tmp_path):
     args = ("--scene", "cubes2048", "--steps", "4", "--cuts", "x:210", "--fp64")
     hip = launch(2, str(tmp_path / "hip"), "--engine", "hipc", *args)
