@@ -145,7 +145,7 @@ int pbf_grid_extent(const pbf_ctx *ctx, uint64_t extent[3], double min_extent[3]
 /* Device self-test of the range-trimmed IEEE sqrt / divide the precise pair terms use (csrc/pbf_kernels.hpp
  * sqrt_ranged / div_ranged) against the compiler's full IEEE forms: mismatches[0] over EVERY fp32 value >= 2^-96,
  * mismatches[1] over (h - r)^2 / r for every fp32 r in [1e-8, h], four h.  Both must be 0. */
-int pbf_selftest_math(pbf_ctx *ctx, uint64_t mismatches[2]);
+int pbf_selftest_math(pbf_ctx *ctx, uint64_t mismatches[4]); /* [2], [3]: x / poly6(0.3 h) and x / RHO over EVERY fp32 x */
 
 /* Mean milliseconds per call of each stage since the last pbf_reset_stage_times (needs
  * PBF_FLAG_STAGE_TIMING).  names[i] points at static strings that follow the reference's Stopwatch

@@ -1258,18 +1258,22 @@ int pbf_read_buffer(pbf_ctx *ctx, int which, void *host, size_t bytes) {
   return PBF_OK;
 }
 
-int pbf_selftest_math(pbf_ctx *ctx, uint64_t mismatches[2]) {
+int pbf_selftest_math(pbf_ctx *ctx, uint64_t mismatches[4]) {
   if (!ctx || !mismatches) return PBF_ERR_INVALID;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (int rc = ensure(ctx, ctx->selTotals, 16)) return rc;
-  HIPCHK(ctx, hipMemsetAsync(ctx->selTotals.p, 0, 16, ctx->stream));
+  if (int rc = ensure(ctx, ctx->selTotals, 64)) return rc;
+  HIPCHK(ctx, hipMemsetAsync(ctx->selTotals.p, 0, 32, ctx->stream));
+  // the two per-launch constant divisors of delta-p for this context's h: poly6(0.3 h) and the reference density
+  const float h = float(ctx->desc.h);
+  const float p6 = poly6_factor<float>(h), r = float(CorrDeltaQ * h), d = (h * h) - r * r;
+  const float p6DeltaQ = p6 * (d * d * d);
   hipLaunchKernelGGL(k_selftest_math, dim3(uint32_t(ctx->numCUs) * 8), dim3(BLOCK), 0, ctx->stream,
-                     ctx->selTotals.as<unsigned long long>());
+                     ctx->selTotals.as<unsigned long long>(), p6DeltaQ, float(RHO));
   LAUNCH_CHECK(ctx);
-  unsigned long long h[2] = {0, 0};
-  HIPCHK(ctx, hipMemcpyAsync(h, ctx->selTotals.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long hst[4] = {0, 0, 0, 0};
+  HIPCHK(ctx, hipMemcpyAsync(hst, ctx->selTotals.p, 32, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  mismatches[0] = h[0], mismatches[1] = h[1];
+  for (int k = 0; k < 4; ++k) mismatches[k] = hst[k];
   return PBF_OK;
 }
 

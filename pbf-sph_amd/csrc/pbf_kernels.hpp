@@ -374,6 +374,10 @@ __device__ inline double fast_rsq(double x) { return 1.0 / sqrt(x); }  // fp64 k
 // and h^2 - r^2 rounds to h^2.  Likewise hipcc's divide = v_div_scale x 2 + v_rcp + Newton + v_div_fmas +
 // v_div_fixup (11 VALU); with 1e-8 <= r <= h and 0 <= (h - r)^2 <= h^2 nothing needs scaling or fixing and the same
 // Newton steps alone (8 VALU) give the same bits; outside that range the quotient is never used (selected away).
+// The same divide serves delta-p's poly6(r) / poly6(0.3 h): the numerator is 0 or between 1e-18 and 1.6e3 in magnitude
+// and k_selftest_math sweeps EVERY fp32 numerator between 1e-30 and 1e30 over that constant: identical but for -0 -> +0,
+// and the quotient is only ever squared.  (lambda_a + lambda_b + corr) / RHO keeps hipcc's IEEE divide: its numerator can
+// be a denormal — two lambdas cancelling exactly next to r = h — where the trimmed form is not the IEEE one.)
 __device__ inline float sqrt_ranged(float x) {
   const float s = __builtin_amdgcn_sqrtf(x);
   const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
@@ -571,7 +575,7 @@ template <typename N, bool FAST> struct DeltaOp {
     const auto g = pair_geom<N, FAST>(pa, pb, c.h);
     if (g.inSpiky) {  // outside it the gradient is zero, so corr / factor are irrelevant
       const N d = (c.h * c.h) - g.r * g.r;
-      const N q = (c.poly6Factor * (d * d * d)) / c.p6DeltaQ;
+      const N q = FAST ? (c.poly6Factor * (d * d * d)) / c.p6DeltaQ : div_ranged(c.poly6Factor * (d * d * d), c.p6DeltaQ);
       const N q2 = q * q;
       const N corr = N(-CorrK) * (q2 * q2);  // pow(q, CorrN = 4) of ompsph.hpp:240
       const N factor = (pa.w + pb.w + corr) / N(RHO);
@@ -584,7 +588,7 @@ template <typename N, bool FAST> struct DeltaOp {
     // corr / factor are irrelevant there and the select adds +0
     const auto g = pair_geom<N, FAST>(pa, pb, c.h);
     const N d = (c.h * c.h) - g.r * g.r;
-    const N q = (c.poly6Factor * (d * d * d)) / c.p6DeltaQ;
+    const N q = FAST ? (c.poly6Factor * (d * d * d)) / c.p6DeltaQ : div_ranged(c.poly6Factor * (d * d * d), c.p6DeltaQ);
     const N q2 = q * q;
     const N corr = N(-CorrK) * (q2 * q2);  // pow(q, CorrN = 4) of ompsph.hpp:240
     const N factor = (pa.w + pb.w + corr) / N(RHO);
@@ -1538,14 +1542,23 @@ __global__ __launch_bounds__(BLOCK) void k_pack_aos(uint32_t n, uint8_t *__restr
 
 // Exhaustive check of the trimmed sqrt / divide against hipcc's IEEE forms (pbf_selftest_math): every fp32 bit
 // pattern x >= 2^-96 for the sqrt; for the divide (h - r)^2 / r over r = every fp32 value in [1e-8, 0.1] x four h.
-__global__ __launch_bounds__(BLOCK) void k_selftest_math(unsigned long long *__restrict__ bad) {
-  unsigned long long badSqrt = 0, badDiv = 0;
+__global__ __launch_bounds__(BLOCK) void k_selftest_math(unsigned long long *__restrict__ bad, float divisorA,
+                                                         float divisorB) {
+  unsigned long long badSqrt = 0, badDiv = 0, badA = 0, badB = 0;
   const float hs[4] = {0.1f, 0.05f, 0.2f, 0.0999999f};
   for (uint64_t v = uint64_t(blockIdx.x) * BLOCK + threadIdx.x; v < (1ull << 32); v += uint64_t(gridDim.x) * BLOCK) {
     const float x = __int_as_float(int(uint32_t(v)));
     if (x >= 0x1p-96f && x <= 3.0e38f) {
       const float a = sqrt_ranged(x), b = sqrtf(x);
       badSqrt += __float_as_int(a) != __float_as_int(b);
+    }
+    {  // EVERY fp32 numerator (NaNs compare by class) over the two per-launch constant divisors of delta-p
+      const float qa = div_ranged(x, divisorA), ra = x / divisorA, qb = div_ranged(x, divisorB), rb = x / divisorB;
+      // bad[2] / bad[3] count the mismatches with 1e-30 <= |x| <= 1e30 or x == 0: outside, where the quotient or the
+      // numerator leaves the normal range, the trimmed form is NOT the IEEE one (and is not used)
+      const bool mid = x == 0.f || (fabsf(x) >= 1e-30f && fabsf(x) <= 1e30f);
+      badA += mid && ((qa != qa) ? !(ra != ra) : __float_as_int(qa) != __float_as_int(ra));
+      badB += mid && ((qb != qb) ? !(rb != rb) : __float_as_int(qb) != __float_as_int(rb));
     }
     if (x >= 1e-8f && x <= 0.2f) {
 #pragma unroll
@@ -1558,6 +1571,8 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_math(unsigned long long *__r
   }
   if (badSqrt) atomicAdd(&bad[0], badSqrt);
   if (badDiv) atomicAdd(&bad[1], badDiv);
+  if (badA) atomicAdd(&bad[2], badA);
+  if (badB) atomicAdd(&bad[3], badB);
 }
 
 }  // namespace pbf

@@ -621,9 +621,11 @@ def test_ranged_sqrt_and_divide_are_the_ieee_ones(pkg):
     v_div_scale / v_div_fixup): swept on the device against the compiler's IEEE forms over every fp32 value
     (sqrt, x >= 2^-96) and every fp32 r in [1e-8, h] for (h - r)^2 / r — not one mismatch allowed."""
     s = pkg.Solver(h=0.1)
-    bad = np.zeros(2, np.uint64)
+    bad = np.zeros(4, np.uint64)
     s._chk(s.L.pbf_selftest_math(s.ctx, bad.ctypes.data_as(C.c_void_p)), "pbf_selftest_math")
-    assert bad[0] == 0 and bad[1] == 0, bad
+    # [2]: x / poly6(0.3 h) over every fp32 x with 1e-30 <= |x| <= 1e30 or x == 0 — one mismatch allowed: -0 -> +0
+    # (the quotient is only ever squared).  [3]: x / RHO is reported, not used (its numerator can be a denormal).
+    assert bad[0] == 0 and bad[1] == 0 and bad[2] <= 1, bad
 
 
 @pytest.mark.parametrize("fp64", [False, True])
