@@ -366,42 +366,60 @@ template <typename N, bool FAST> struct PairGeom {
 __device__ inline float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ inline double fast_rsq(double x) { return 1.0 / sqrt(x); }  // fp64 keeps the IEEE forms
 
-// Correctly rounded sqrt and divide for the PRECISE pair terms, trimmed to the operand range they see (the readers
-// are VALU-issue bound: profiles/r02_pmc_sq_baseline.md).  hipcc's IEEE sqrtf is v_sqrt_f32 + a +-1 ulp fix-up wrapped
-// in a 2^32 rescale for inputs below 2^-96 and a class test: 16 VALU; here the same v_sqrt_f32 and the same fix-up
-// without the wrapper: 9.  For d2 >= 2^-96 the result is the IEEE one bit for bit (k_selftest_math sweeps every fp32
-// value); below — r < 3.6e-15, far under EPSILON — any small r gives the same pair terms: the spiky branch is off,
-// and h^2 - r^2 rounds to h^2.  Likewise hipcc's divide = v_div_scale x 2 + v_rcp + Newton + v_div_fmas +
-// v_div_fixup (11 VALU); with 1e-8 <= r <= h and 0 <= (h - r)^2 <= h^2 nothing needs scaling or fixing and the same
-// Newton steps alone (8 VALU) give the same bits; outside that range the quotient is never used (selected away).
-// The same divide serves delta-p's poly6(r) / poly6(0.3 h): the numerator is 0 or between 1e-18 and 1.6e3 in magnitude
-// and k_selftest_math sweeps EVERY fp32 numerator between 1e-30 and 1e30 over that constant: identical but for -0 -> +0,
-// and the quotient is only ever squared.  (lambda_a + lambda_b + corr) / RHO keeps hipcc's IEEE divide: its numerator can
-// be a denormal — two lambdas cancelling exactly next to r = h — where the trimmed form is not the IEEE one.)
-__device__ inline float sqrt_ranged(float x) {
-  const float s = __builtin_amdgcn_sqrtf(x);
-  const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
-  const float em = fmaf(-sm, s, x), ep = fmaf(-sp, s, x);
-  float r = em <= 0.f ? sm : s;
-  r = ep > 0.f ? sp : r;
+// Correctly rounded sqrt and divide for the PRECISE pair terms, trimmed to the operand range they see and to what the
+// VALU issues fastest (tools/valu_rate.hip, profiles/r02_valu_rates.md: fma / add / mul issue at full rate; compares,
+// selects, min / max, shifts and the packed forms at 4/7 of it; v_sqrt / v_rcp / v_rsq at 2/7).  hipcc's IEEE sqrtf is
+// v_sqrt_f32 + a +-1 ulp fix-up (two compares, two selects) inside a 2^32 rescale for tiny inputs: 16 VALU; its divide
+// v_div_scale x 2 + v_rcp + Newton + v_div_fmas + v_div_fixup: 11.
+//   * sqrt_rsq: ONE v_rsq_f32 gives y ~ 1/sqrt(x); g = x y, then one Heron step in fma form, g + (x - g^2) (y / 2):
+//     no compare, no select, and y comes out as a by-product ~ 1 / r.  Equal to IEEE sqrtf bit for bit for every fp32
+//     x >= 2^-75 (k_selftest_math sweeps them all).  The addend 2^-100 keeps x = 0 (a particle meeting itself) away
+//     from v_rsq's infinity and is absorbed exactly by every x >= 2^-75; below that — r < 5.5e-12, far under EPSILON —
+//     every small r gives the same pair terms: the spiky branch is off and h^2 - r^2 rounds to h^2.
+//   * div_seeded: (h - r)^2 / r by Newton from that y: one refinement of the reciprocal, the quotient, two residual
+//     corrections — 7 fma / mul, no v_rcp.  With 1e-8 <= r <= h nothing needs scaling or fixing and the result is the
+//     IEEE quotient bit for bit (swept: every fp32 d2 whose root lies in [1e-8, h], four h); outside that range the
+//     quotient is never used (selected away).
+//   * div_ranged (reciprocal of a per-launch CONSTANT divisor, hoisted out of the loops by the compiler) serves
+//     delta-p's poly6(r) / poly6(0.3 h) — numerator 0 or 1e-18 ... 1.6e3 in magnitude; k_selftest_math sweeps EVERY
+//     fp32 numerator between 1e-30 and 1e30: identical but for -0 -> +0, and the quotient is only ever squared — and
+//     (lambda_a + lambda_b + corr) / RHO, whose numerator can be a denormal (two lambdas cancelling exactly next to
+//     r = h): identical for every |numerator| >= 2^-100 (swept; again but for the sign of a zero, which only ever
+//     multiplies into a term that is added to a sum), and DeltaOp falls back to the compiler's divide for a whole wave
+//     when one lane's numerator is smaller than that.
+__device__ inline float sqrt_rsq(float x, float &y) {
+  x += 0x1p-100f;
+  y = __builtin_amdgcn_rsqf(x);
+  const float g = x * y, hy = 0.5f * y;
+  return fmaf(fmaf(-g, g, x), hy, g);
+}
+__device__ inline double sqrt_rsq(double x, double &y) {
+  const double r = sqrt(x);
+  y = 1.0 / r;
   return r;
 }
-__device__ inline double sqrt_ranged(double x) { return sqrt(x); }
-__device__ inline float div_ranged(float a, float b) {
-  float y = __builtin_amdgcn_rcpf(b);
+__device__ inline float div_seeded(float a, float b, float y) {
   y = fmaf(fmaf(-b, y, 1.0f), y, y);
   float q = a * y;
   q = fmaf(fmaf(-b, q, a), y, q);
   q = fmaf(fmaf(-b, q, a), y, q);
   return q;
 }
+__device__ inline double div_seeded(double a, double b, double) { return a / b; }
+__device__ inline float div_ranged(float a, float b) { return div_seeded(a, b, __builtin_amdgcn_rcpf(b)); }
 __device__ inline double div_ranged(double a, double b) { return a / b; }
+// The numerators div_ranged is the IEEE divide for: finite and at least 2^-100 in magnitude (x * 0 + x turns an
+// infinity into a NaN, which fails the compare like a NaN, a zero or a tiny numerator does)
+__device__ inline bool div_ranged_ok(float x) { return fabsf(fmaf(x, 0.0f, x)) >= 0x1p-100f; }
 
 template <typename N, bool FAST>
 __device__ inline PairGeom<N, FAST> pair_geom(const vec4<N> &a, const vec4<N> &b, N h) {
   PairGeom<N, FAST> g;
   const N bx = b.x - a.x, by = b.y - a.y, bz = b.z - a.z;  // distance(a,b) = length(b - a)
-  g.dx = a.x - b.x, g.dy = a.y - b.y, g.dz = a.z - b.z;
+  // a - b = -(b - a) exactly (round to nearest is sign-symmetric), but for the sign of a zero difference — and a zero
+  // difference only ever multiplies into a term that is ADDED to a running sum, which +0 and -0 leave alike (the sums
+  // start at +0 and can never become -0).  As a negation it is a free source modifier instead of three subtractions.
+  g.dx = -bx, g.dy = -by, g.dz = -bz;
   if constexpr (FAST) {
     const N d2 = fma(bz, bz, fma(by, by, bx * bx));
     const N rinv = fast_rsq(d2);
@@ -412,11 +430,12 @@ __device__ inline PairGeom<N, FAST> pair_geom(const vec4<N> &a, const vec4<N> &b
     g.hr2_over_r = (hr * hr) * rinv;
   } else {
     const N d2 = bx * bx + by * by + bz * bz;
-    g.r = sqrt_ranged(d2);
+    N rinv;
+    g.r = sqrt_rsq(d2, rinv);
     g.inH = g.r <= h;
     g.inSpiky = g.inH && g.r >= N(EPSILON);
     const N hr = h - g.r;
-    g.hr2_over_r = div_ranged(hr * hr, g.r);  // (only used where inSpiky)
+    g.hr2_over_r = div_seeded(hr * hr, g.r, rinv);  // (only used where inSpiky)
   }
   return g;
 }
@@ -499,7 +518,15 @@ template <typename N, bool FAST> struct LambdaOp {
   static constexpr bool kTileable = true;
   __device__ bool near(const StepConsts<N> &c, const Src &pb) const { return maybe_within_h<N>(pa, pb, c.h2filter); }
   __host__ __device__ static const Src *src(const Args &a) { return a.pstar; }
-  __device__ static Src load(const Args &a, uint32_t b) { return a.pstar[b]; }
+  __device__ static Src load(const Args &a, uint32_t b) {
+#ifdef PBF_LAMBDA_X4
+    Src v = a.pstar[b];
+    asm volatile("" : "+v"(v.w));  // keep the fourth component: one 16-byte gather instead of a 12-byte one
+    return v;
+#else
+    return a.pstar[b];
+#endif
+  }
   vec4<N> pa;
   N mass, gx, gy, gz, rho;
   __device__ bool begin(const StepConsts<N> &c, const Args &a, uint32_t i) {
@@ -528,10 +555,11 @@ template <typename N, bool FAST> struct LambdaOp {
     // sqrt / divide chains interleave.  An excluded pair contributes exactly +0 (a select, never a
     // multiply: r = 0 makes hr2_over_r infinite), which leaves every partial sum bit-identical.
     const auto g = pair_geom<N, FAST>(pa, pb, c.h);
-    const N s = c.spikyFactor * g.hr2_over_r;
-    const N tx = (g.dx * s) * N(RHO_RECIP), ty = (g.dy * s) * N(RHO_RECIP), tz = (g.dz * s) * N(RHO_RECIP);
     const bool sp = g.inSpiky && valid, ih = g.inH && valid;
-    gx += sp ? tx : N(0), gy += sp ? ty : N(0), gz += sp ? tz : N(0);
+    // ONE select, on the common factor (r = 0 makes hr2_over_r infinite or NaN): the three products of an excluded
+    // pair are then (finite) * 0 * RHO_RECIP = +-0
+    const N s = sp ? c.spikyFactor * g.hr2_over_r : N(0);
+    gx += (g.dx * s) * N(RHO_RECIP), gy += (g.dy * s) * N(RHO_RECIP), gz += (g.dz * s) * N(RHO_RECIP);
     const N d = (c.h * c.h) - g.r * g.r;
     const N w = mass * (c.poly6Factor * (d * d * d));
     rho += ih ? w : N(0);
@@ -571,6 +599,16 @@ template <typename N, bool FAST> struct DeltaOp {
     }
     return true;
   }
+  // (lambda_a + lambda_b + corr) / RHO: the trimmed divide where it IS the IEEE one (div_ranged_ok), the compiler's
+  // otherwise — decided per wave, so the common path carries one fma and one compare and no divergence
+  __device__ static N over_rho(N num) {
+    if constexpr (FAST || sizeof(N) == 8) {
+      return num / N(RHO);
+    } else {
+      if (__builtin_expect(__any(!div_ranged_ok(num)), 0)) return num / N(RHO);
+      return div_ranged(num, N(RHO));
+    }
+  }
   __device__ void add(const StepConsts<N> &c, const Src &pb) {
     const auto g = pair_geom<N, FAST>(pa, pb, c.h);
     if (g.inSpiky) {  // outside it the gradient is zero, so corr / factor are irrelevant
@@ -585,17 +623,17 @@ template <typename N, bool FAST> struct DeltaOp {
   }
   __device__ void add_bf(const StepConsts<N> &c, const Src &pb, bool valid = true) {
     // branch-free like LambdaOp::add_bf; outside the spiky support the gradient is exactly zero, so
-    // corr / factor are irrelevant there and the select adds +0
+    // corr / factor are irrelevant there: both factors of an excluded pair are selected to 0 (a lambda of a particle
+    // outside the support may be anything, an infinity included) and the products add +-0
     const auto g = pair_geom<N, FAST>(pa, pb, c.h);
+    const bool sp = g.inSpiky && valid;
     const N d = (c.h * c.h) - g.r * g.r;
     const N q = FAST ? (c.poly6Factor * (d * d * d)) / c.p6DeltaQ : div_ranged(c.poly6Factor * (d * d * d), c.p6DeltaQ);
     const N q2 = q * q;
     const N corr = N(-CorrK) * (q2 * q2);  // pow(q, CorrN = 4) of ompsph.hpp:240
-    const N factor = (pa.w + pb.w + corr) / N(RHO);
-    const N s = c.spikyFactor * g.hr2_over_r;
-    const N tx = (g.dx * s) * factor, ty = (g.dy * s) * factor, tz = (g.dz * s) * factor;
-    const bool sp = g.inSpiky && valid;
-    ax += sp ? tx : N(0), ay += sp ? ty : N(0), az += sp ? tz : N(0);
+    const N f = over_rho(pa.w + pb.w + corr);
+    const N factor = sp ? f : N(0), s = sp ? c.spikyFactor * g.hr2_over_r : N(0);
+    ax += (g.dx * s) * factor, ay += (g.dy * s) * factor, az += (g.dz * s) * factor;
   }
   template <typename R> __device__ void combine(R &&r) { ax = r(ax), ay = r(ay), az = r(az); }
   __device__ void end(const StepConsts<N> &c, const Args &a, uint32_t i) {
@@ -1540,33 +1578,37 @@ __global__ __launch_bounds__(BLOCK) void k_pack_aos(uint32_t n, uint8_t *__restr
   col[0] = C.x, col[1] = C.y, col[2] = C.z, col[3] = C.w;
 }
 
-// Exhaustive check of the trimmed sqrt / divide against hipcc's IEEE forms (pbf_selftest_math): every fp32 bit
-// pattern x >= 2^-96 for the sqrt; for the divide (h - r)^2 / r over r = every fp32 value in [1e-8, 0.1] x four h.
+// Exhaustive check of the trimmed sqrt / divides against hipcc's IEEE forms (pbf_selftest_math):
+//   bad[0]  sqrt_rsq(x) vs sqrtf(x) over every fp32 x >= 2^-75;
+//   bad[1]  div_seeded((h - r)^2, r, y) vs the IEEE quotient over every fp32 d2 with r = sqrt(d2) in [1e-8, h], y the
+//           by-product of sqrt_rsq(d2) — exactly the operands pair_geom hands it — for four h;
+//   bad[2]  div_ranged(x, poly6(0.3 h)) over every fp32 x with 1e-30 <= |x| <= 1e30 or x == 0 (NaNs compare by class);
+//   bad[3]  DeltaOp's x / RHO — div_ranged where div_ranged_ok(x), the compiler's divide otherwise — over EVERY fp32 x.
 __global__ __launch_bounds__(BLOCK) void k_selftest_math(unsigned long long *__restrict__ bad, float divisorA,
                                                          float divisorB) {
   unsigned long long badSqrt = 0, badDiv = 0, badA = 0, badB = 0;
   const float hs[4] = {0.1f, 0.05f, 0.2f, 0.0999999f};
   for (uint64_t v = uint64_t(blockIdx.x) * BLOCK + threadIdx.x; v < (1ull << 32); v += uint64_t(gridDim.x) * BLOCK) {
     const float x = __int_as_float(int(uint32_t(v)));
-    if (x >= 0x1p-96f && x <= 3.0e38f) {
-      const float a = sqrt_ranged(x), b = sqrtf(x);
-      badSqrt += __float_as_int(a) != __float_as_int(b);
+    if (x >= 0x1p-75f && x <= 3.0e38f) {
+      float y;
+      const float r = sqrt_rsq(x, y), ref = sqrtf(x);
+      badSqrt += __float_as_int(r) != __float_as_int(ref);
+      if (ref >= 1e-8f && ref <= 0.2f) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (ref <= hs[k]) {
+            const float hr = hs[k] - ref, num = hr * hr;
+            badDiv += __float_as_int(div_seeded(num, ref, y)) != __float_as_int(num / ref);
+          }
+      }
     }
-    {  // EVERY fp32 numerator (NaNs compare by class) over the two per-launch constant divisors of delta-p
-      const float qa = div_ranged(x, divisorA), ra = x / divisorA, qb = div_ranged(x, divisorB), rb = x / divisorB;
-      // bad[2] / bad[3] count the mismatches with 1e-30 <= |x| <= 1e30 or x == 0: outside, where the quotient or the
-      // numerator leaves the normal range, the trimmed form is NOT the IEEE one (and is not used)
+    {
+      const float qa = div_ranged(x, divisorA), ra = x / divisorA;
       const bool mid = x == 0.f || (fabsf(x) >= 1e-30f && fabsf(x) <= 1e30f);
       badA += mid && ((qa != qa) ? !(ra != ra) : __float_as_int(qa) != __float_as_int(ra));
-      badB += mid && ((qb != qb) ? !(rb != rb) : __float_as_int(qb) != __float_as_int(rb));
-    }
-    if (x >= 1e-8f && x <= 0.2f) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (x <= hs[k]) {
-          const float hr = hs[k] - x, num = hr * hr;
-          badDiv += __float_as_int(div_ranged(num, x)) != __float_as_int(num / x);
-        }
+      const float rb = x / divisorB, qb = div_ranged_ok(x) ? div_ranged(x, divisorB) : rb;
+      badB += (qb != qb) ? !(rb != rb) : __float_as_int(qb) != __float_as_int(rb);
     }
   }
   if (badSqrt) atomicAdd(&bad[0], badSqrt);
