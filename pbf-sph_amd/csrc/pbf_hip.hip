@@ -17,6 +17,7 @@
 
 #include "pbf_kernels.hpp"
 #include "pbf_slab.hpp"
+#include "pbf_tiles.hpp"
 #include "pbf_mc.hpp"
 #include "pbf_comm.hpp"
 
@@ -485,7 +486,58 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
     LAUNCH_CHECK(ctx);
     return PBF_OK;
   }
-  if (ctx->gatherKind == 1) {
+  if constexpr (Op::kTileable && Op::kFilter) {
+    // gather = 3: the solver iteration per brick out of LDS tiles (pbf_tiles.hpp); everything else it does not cover
+    // (diffuse, the opt-in extras) takes the list path below
+    if (ctx->gatherKind == 3 && mode != GATHER_PLAIN && uint64_t(ctx->n) * sizeof(typename Op::Src) <= 0xFFFFFFFFull) {
+      using B = TileBrick;
+      static_assert(kBrickZ == TILE_BZ, "the sort stage's brick list is the tile kernels' one");
+      constexpr int WAYS = 4, LMAX = 16;
+      uint32_t cap = ctx->tileCap ? std::min(ctx->tileCap, 65535u) : 2048u;  // list entries of a tiled brick are tile slots
+      uint32_t *nl = ctx->nbrList.as<uint32_t>(), *nc = ctx->nbrCount.as<uint32_t>();
+      uint32_t *ctl = ctx->brickCtl.as<uint32_t>();
+      auto ticket = [&]() -> uint32_t * {
+        if (ctx->gatherSeq >= kTickets) {  // more launches than tickets since the last sort: re-arm
+          (void)hipMemsetAsync(ctl + 1, 0, kTickets * 4, ctx->stream);
+          ctx->gatherSeq = 0;
+        }
+        return ctl + 1 + ctx->gatherSeq++;
+      };
+      auto launch_dims = [&](const void *kernel, size_t lds, size_t &attrSet) {
+        if (lds > attrSet) {
+          (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+          attrSet = lds;
+        }
+        const uint32_t perCU = uint32_t(std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 512))));
+        return dim3(uint32_t(ctx->numCUs) * perCU);
+      };
+      if (mode == GATHER_SAVE_LISTS) {
+        uint2 *qp = ctx->qpos.as<uint2>();
+        if (!ctx->qposValid) {
+          hipLaunchKernelGGL((k_quantise<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, Op::src(args), qp);
+          ctx->qposValid = true;
+        }
+        StageTimer tb(ctx, ST_BUILD);
+        const size_t lds = B::HDR2 + size_t(cap + WAYS) * sizeof(uint2) + size_t(LMAX + WAYS) * TILE_THREADS * 2;
+        if (lds > 160 * 1024 - 64) return fail(ctx, PBF_ERR_INVALID, "tile cap exceeds the CU's 160 KiB LDS");
+        auto kernel = k_tile_build<N, WAYS, LMAX>;
+        static size_t attrSet = 0;
+        const dim3 grid = launch_dims(reinterpret_cast<const void *>(kernel), lds, attrSet);
+        hipLaunchKernelGGL(kernel, grid, dim3(TILE_THREADS), lds, ctx->stream, c, Op::src(args), qp, args.type, key, table,
+                           ctx->bricks.as<const uint32_t>(), ctl, ticket(), cap, nl, nc);
+      }
+      const size_t lds = B::HDR2 + size_t(cap) * sizeof(typename Op::Src);
+      if (lds > 160 * 1024 - 64) return fail(ctx, PBF_ERR_INVALID, "tile cap exceeds the CU's 160 KiB LDS");
+      auto kernel = k_tile_from_lists<N, Op>;
+      static size_t attrSet = 0;  // per instantiation
+      const dim3 grid = launch_dims(reinterpret_cast<const void *>(kernel), lds, attrSet);
+      hipLaunchKernelGGL(kernel, grid, dim3(TILE_THREADS), lds, ctx->stream, c, args, key, table,
+                         ctx->bricks.as<const uint32_t>(), ctl, ticket(), cap, nl, nc);
+      LAUNCH_CHECK(ctx);
+      return PBF_OK;
+    }
+  }
+  if (ctx->gatherKind == 1 || ctx->gatherKind == 3) {
     uint32_t *nl = ctx->nbrList.as<uint32_t>(), *nc = ctx->nbrCount.as<uint32_t>();
     const dim3 g = grid_for(ctx->n), b(BLOCK);
     auto from_lists = [&]() {  // the list-driven reader: one lane per particle, or (option "coop") a lane group per particle
@@ -637,7 +689,7 @@ template <typename N> int stage_lambda(pbf_ctx *ctx, const pbf_params *p) {
   StageTimer t(ctx, ST_LAMBDA);
   const int s = ctx->cur;
   // the survivors of lambda's filter are exactly delta's (same pStar): hand them over through HBM
-  const bool lists = ctx->gatherKind == 1 && ctx->reuseLists && !(ctx->desc.flags & PBF_FLAG_NO_LDS);
+  const bool lists = (ctx->gatherKind == 1 || ctx->gatherKind == 3) && ctx->reuseLists && !(ctx->desc.flags & PBF_FLAG_NO_LDS);
   const GatherMode save = lists ? GATHER_SAVE_LISTS : GATHER_PLAIN;
   ctx->nbrValid = lists;
   if (lists && ctx->fuseDiffuseNow) {  // pbf_step: the colour diffusion rides on this launch's walk

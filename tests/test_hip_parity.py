@@ -74,12 +74,12 @@ def assert_state_equal(g, w, what=""):
 SCENES = ["cubes8192", "dam8192"]
 
 
-@pytest.fixture(params=["default", "global", "bricks"])
+@pytest.fixture(params=["default", "global", "bricks", "tiles"])
 def variant(request):
     """The gather kernels must all be bit-identical to the oracle: None = the product default (1 = neighbour
     lists: quantised build + list-driven lambda / delta-p, per-cell diffuse), 0 = per-particle global walk,
     2 = persistent LDS bricks."""
-    return {"default": None, "global": 0, "bricks": 2}[request.param]
+    return {"default": None, "global": 0, "bricks": 2, "tiles": 3}[request.param]
 
 # ------------------------------------------------------------------------------------------ A
 
