@@ -76,6 +76,20 @@ __global__ __launch_bounds__(BLOCK) void k_predict(StepConsts<N> c, const vec4<N
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = BLOCK * SCAN_ITEMS;
 
+// Workgroup -> chunk of the sorted particle array, XCD-aware.  The dispatcher deals consecutive workgroup ids round
+// robin over the 8 XCDs, each with an L2 of its own, so with chunk = blockIdx two neighbouring chunks — which share most
+// of their candidates — never share an L2.  Here XCD k works on the k-th contiguous eighth of the chunks: neighbours in
+// the Morton order meet in one L2 (a bijection of [0, gridDim) for any grid size).
+constexpr uint32_t NUM_XCD = 8;
+__device__ inline uint32_t xcd_chunk() {
+#ifdef PBF_NO_XCD_MAP
+  return blockIdx.x;
+#else
+  const uint32_t g = gridDim.x, k = blockIdx.x % NUM_XCD, q = g / NUM_XCD, r = g % NUM_XCD;
+  return k * q + min(k, r) + blockIdx.x / NUM_XCD;
+#endif
+}
+
 __device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -1308,7 +1322,8 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const 
   static_assert(4 * W + 2 <= QPOS_PAD, "qpos padding");
   __shared__ uint32_t list[(LMAX + 2 * W) * BLOCK];  // per-lane staging: a trip appends up to 2 W past LMAX - 1
   const uint32_t tid = threadIdx.x;
-  const uint32_t i = blockIdx.x * BLOCK + tid;
+  const uint32_t chunk = xcd_chunk();
+  const uint32_t i = chunk * BLOCK + tid;
   if (i >= c.n) return;
   if (c.hasObstacles && type[i] != 0) {
     nbrCount[i] = 0;
@@ -1324,7 +1339,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const 
     const qpair dxy = __builtin_bit_cast(qpair, qx) - axy, dzw = __builtin_bit_cast(qpair, qy) - azw;
     return uint32_t(qdot2(__builtin_bit_cast(uint32_t, dzw), qdot2(__builtin_bit_cast(uint32_t, dxy)))) <= t2;
   };
-  uint32_t *blk = nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK;
+  uint32_t *blk = nbrList + size_t(chunk) * NBR_CAP * BLOCK;
   uint32_t written = 0, nl = 0;
   auto flush = [&]() {
     for (uint32_t q = 0; __any(q < nl); ++q)
@@ -1418,12 +1433,13 @@ __global__ __launch_bounds__(BLOCK) void k_gather_from_lists(StepConsts<N> c, ty
                                                              const uint32_t *__restrict__ nbrList,
                                                              const uint32_t *__restrict__ nbrCount) {
   const uint32_t tid = threadIdx.x;
-  const uint32_t i = blockIdx.x * BLOCK + tid;
+  const uint32_t chunk = xcd_chunk();
+  const uint32_t i = chunk * BLOCK + tid;
   if (i >= c.n) return;
   Op op;
   if (!op.begin(c, args, i)) return;
   const uint32_t cnt = nbrCount[i];
-  const uint32_t *mine = nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK + tid;
+  const uint32_t *mine = nbrList + size_t(chunk) * NBR_CAP * BLOCK + tid;
   if (cnt == NBR_OVERFLOW) {
     for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { op.add(c, Op::load(args, b)); });
   } else if constexpr (PIPELINED) {
@@ -1485,7 +1501,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_from_lists_coop(StepConsts<N> 
   static_assert(COOP == 2 || COOP == 4 || COOP == 8, "group size");
   constexpr uint32_t PER_BLOCK = BLOCK / COOP;  // particles per workgroup
   const uint32_t sub = threadIdx.x % COOP;
-  const uint32_t i = blockIdx.x * PER_BLOCK + threadIdx.x / COOP;
+  const uint32_t i = xcd_chunk() * PER_BLOCK + threadIdx.x / COOP;
   // (no early return: every lane of a group takes part in the shuffles; a group past the end only idles)
   const bool live = i < c.n;
   Op op;
