@@ -832,7 +832,7 @@ template <typename N, typename Op>
 __global__ __launch_bounds__(BLOCK) void k_gather_global(StepConsts<N> c, typename Op::Args args,
                                                          const uint32_t *__restrict__ key,
                                                          const uint32_t *__restrict__ table) {
-  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  const uint32_t i = xcd_chunk() * BLOCK + threadIdx.x;
   if (i >= c.n) return;
   gather_one_global<N, Op>(c, args, key, table, i);
 }
@@ -1189,7 +1189,8 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
   constexpr bool FUSED = !std::is_same<Extra, NoExtra>::value;
   __shared__ uint32_t list[(Op::kFilter ? LMAX + 4 : 1) * BLOCK];  // +4: a trip appends up to WAYS past LMAX - 1
   const uint32_t tid = threadIdx.x;
-  const uint32_t i = blockIdx.x * BLOCK + tid;
+  const uint32_t chunk = xcd_chunk();
+  const uint32_t i = chunk * BLOCK + tid;
   if (i >= c.n) return;
   if constexpr (!Op::kFilter) {  // diffuse has no distance test: nothing to filter, plain (2-way) walk
     gather_one_global<N, Op>(c, args, key, table, i);
@@ -1205,7 +1206,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
   // From here on control flow is WAVE-UNIFORM over the lanes that are left (loop conditions are
   // __any votes): every drain is executed by all of them together.
   uint32_t nl = 0, written = 0;
-  uint32_t *mine = SAVE ? nbrList + size_t(blockIdx.x) * NBR_CAP * BLOCK + tid : nullptr;
+  uint32_t *mine = SAVE ? nbrList + size_t(chunk) * NBR_CAP * BLOCK + tid : nullptr;
   auto drain = [&]() {
 #pragma unroll 2
     for (uint32_t q = 0; __any(q < nl); ++q) {
