@@ -23,6 +23,31 @@ template <typename N> __device__ inline int64_t cell_coord(N v) {
   return static_cast<int64_t>(v);
 }
 
+// One atomic per distinct bucket per WAVE instead of one per lane: the particles arrive in the previous step's Z order,
+// so the 64 lanes of a wave fall into ~10 cells.  Every lane gets the value the bucket held before the wave's add and its
+// rank among the wave's lanes of the same bucket (the histogram only needs the side effect; the scatter turns the two
+// into its slot).  The loop runs once per distinct bucket of the wave and every lane leaves it.
+template <typename F> __device__ inline void wave_bucket_atomic(uint32_t bucket, F &&leader_op, uint32_t &before, uint32_t &rank) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t below = (1ull << lane) - 1ull;
+  bool pending = true;
+  before = 0, rank = 0;
+  while (__any(pending)) {
+    if (pending) {
+      const uint32_t b = __builtin_amdgcn_readfirstlane(bucket);  // the first pending lane's bucket
+      if (bucket == b) {
+        const uint64_t same = __ballot(1);  // the pending lanes of that bucket
+        const uint32_t cnt = uint32_t(__builtin_popcountll(same));
+        rank = uint32_t(__builtin_popcountll(same & below));
+        uint32_t v = 0;
+        if (rank == 0) v = leader_op(b, cnt);
+        before = __builtin_amdgcn_readfirstlane(v);  // (the first active lane is the one of rank 0)
+        pending = false;
+      }
+    }
+  }
+}
+
 template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_predict(StepConsts<N> c, const vec4<N> *__restrict__ pos4,
                                                    vec4<N> *__restrict__ vel4, const uint8_t *__restrict__ type,
@@ -65,7 +90,8 @@ __global__ __launch_bounds__(BLOCK) void k_predict(StepConsts<N> c, const vec4<N
                                    static_cast<uint32_t>(cell_coord((pz - c.minExtent[2]) / c.h)));
   key[i] = k;
   // bucket tableN collects particles outside the table: they are "in no cell" (sph.hpp:206)
-  atomicAdd(&count[min(k, c.tableN)], 1u);
+  uint32_t before, rank;
+  wave_bucket_atomic(min(k, c.tableN), [&](uint32_t b, uint32_t cnt) { return atomicAdd(&count[b], cnt); }, before, rank);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -212,7 +238,9 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_slots(uint32_t n, uint32_t ta
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint32_t b = min(key[i], tableN);
-  const uint32_t r = atomicSub(&count[b], 1u) - 1u;  // r runs m - 1 .. 0 over the cell's m members
+  uint32_t before, rank;
+  wave_bucket_atomic(b, [&](uint32_t bb, uint32_t cnt) { return atomicSub(&count[bb], cnt); }, before, rank);
+  const uint32_t r = before - 1u - rank;  // r runs m - 1 .. 0 over the cell's m members (which member gets which: arbitrary)
   permTmp[table[b] + r] = i;
   if (r == BIG_CELL) bigCells[atomicAdd(nBig, 1u)] = b;  // exactly one member of a cell with m > BIG_CELL sees this
 }
