@@ -568,8 +568,12 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
         StageTimer tb(ctx, ST_BUILD);
         if (ctx->splitBuild == 4)
           hipLaunchKernelGGL((k_build_lists_q<N, 2>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc);
-        else
-          hipLaunchKernelGGL((k_build_lists_q<N, 4>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc);
+        else  // staging depth (option "list_max", default 32: one flush for most particles beats the two more workgroups per CU that 16 leaves room for: -2 % per step)
+          switch (ctx->listMax ? ctx->listMax : 32u) {
+            case 16: hipLaunchKernelGGL((k_build_lists_q<N, 4, 16>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc); break;
+            case 24: hipLaunchKernelGGL((k_build_lists_q<N, 4, 24>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc); break;
+            default: hipLaunchKernelGGL((k_build_lists_q<N, 4, 32>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc); break;
+          }
       }
       from_lists();
     } else if (mode == GATHER_SAVE_LISTS) {
