@@ -127,8 +127,8 @@ def test_every_stage_bit_exact(pkg, oracle, scene, fp64, variant):
 @pytest.mark.parametrize("scene", SCENES)
 def test_free_running_bit_exact(pkg, oracle, scene, fp64, variant):
     """12 frames without re-seeding: GPU state == oracle(device_pow) state, bit for bit."""
-    if variant is not None and fp64 and scene == "cubes8192":
-        pytest.skip("alternative gather kernels: fp64 is covered on the dam-break scene (suite time)")
+    if variant is not None and scene == "cubes8192" and (fp64 or variant != 3):
+        pytest.skip("alternative gather kernels run the dam-break scene (fp32 + fp64); the brick tiles also the cubes in fp32 (suite time)")
     sc, side = get_scene(pkg, scene, fp64)
     s, o = mk(pkg, oracle, sc, fp64, gather=variant)
     p, q = params_pair(pkg, oracle, side=side)
