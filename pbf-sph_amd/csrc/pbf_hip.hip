@@ -649,7 +649,11 @@ template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p, bool 
     vec4<N> *cellSum = ctx->pstar[other_pstar(ctx)].as<vec4<N>>();
     uint32_t *cellCnt = ctx->nbrCount.as<uint32_t>();
     hipStream_t st = ctx->stream;
-    const uint32_t cap = sizeof(vec4<N>) == 16 ? 3072u : 1536u;  // 48 KiB of colours: 216 cells x 14 (7) particles
+    uint32_t cap = sizeof(vec4<N>) == 16 ? 3072u : 1536u;  // 48 KiB of colours: 216 cells x 14 (7) particles
+    // beside the solver iterations: a 32-KiB tile (fp32) leaves room for THREE of the list build's 40-KiB workgroups on
+    // the CU instead of two (measured: step -2.6 %; p99 of the settled dam-break's halos is 1 800 records, a fuller
+    // brick walks globally)
+    if (overlap && sizeof(vec4<N>) == 16) cap = 2048u;
     const size_t lds = Brick<4>::HDR + size_t(cap) * sizeof(vec4<N>);
     uint32_t perCU = uint32_t((160 * 1024) / (lds + 1024));
     if (overlap) {

@@ -31,21 +31,23 @@ template <typename F> __device__ inline void wave_bucket_atomic(uint32_t bucket,
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t below = (1ull << lane) - 1ull;
   bool pending = true;
-  before = 0, rank = 0;
-  while (__any(pending)) {
+  uint32_t cnt = 0, leader = lane;
+  rank = 0;
+  while (__any(pending)) {  // phase 1: who shares my bucket (no memory traffic)
     if (pending) {
       const uint32_t b = __builtin_amdgcn_readfirstlane(bucket);  // the first pending lane's bucket
       if (bucket == b) {
         const uint64_t same = __ballot(1);  // the pending lanes of that bucket
-        const uint32_t cnt = uint32_t(__builtin_popcountll(same));
+        cnt = uint32_t(__builtin_popcountll(same));
         rank = uint32_t(__builtin_popcountll(same & below));
-        uint32_t v = 0;
-        if (rank == 0) v = leader_op(b, cnt);
-        before = __builtin_amdgcn_readfirstlane(v);  // (the first active lane is the one of rank 0)
+        leader = uint32_t(__builtin_ctzll(same));
         pending = false;
       }
     }
   }
+  uint32_t v = 0;
+  if (rank == 0) v = leader_op(bucket, cnt);  // phase 2: the leaders' atomics are all in flight together
+  before = __shfl(v, int(leader), 64);
 }
 
 template <typename N>
