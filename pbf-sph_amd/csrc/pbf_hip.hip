@@ -138,10 +138,11 @@ struct pbf_ctx {
   bool haveParams = false;
   bool qposValid = false;    // qpos is the quantised copy of pstar[pcur] (written by the sort, delta-p and the slab refresh)
   bool reuseLists = true;    // option "reuse_lists"
-  // option "split_build": 0 = lambda builds the neighbour lists while it gathers (k_gather_lists<SAVE>); otherwise the
-  // build is a launch of its own (k_build_lists_q on quantised pairs: 4 = 2 loads per trip, anything else = 4 loads per
-  // trip) followed by a list-driven lambda.  (Round 1's intermediate build kernels, values 1-3, are gone.)
-  int splitBuild = 5;
+  // option "split_build": 0 = lambda builds the neighbour lists while it gathers on fp32 candidates (k_gather_lists<SAVE>);
+  // 4 / 5 = the build is a launch of its own (k_build_lists_q on quantised pairs, 2 / 4 pair loads per trip) followed by a
+  // list-driven lambda; 8 (default) = the quantised build with lambda riding on its flushes (k_build_lists_op: one launch,
+  // no list read for lambda).  (Round 1's intermediate build kernels, values 1-3, are gone.)
+  int splitBuild = 8;
   int pipeline = -1;         // option "pipeline": software-pipelined list readers (bit-identical either way); -1 = auto:
                              // fp64 only (measured at 1 M: fp64 -1.3 %, fp32 +3 % — fp32's readers are VALU-issue bound)
   int coop = 0;              // option "coop": 0 = one lane per particle (bit-exact), 2 / 4 / 8 = lanes sharing a particle's
@@ -564,6 +565,12 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
         if (!ctx->qposValid) {  // (only after a stage that moved pStar without refreshing its quantised copy)
           hipLaunchKernelGGL((k_quantise<N>), g, b, 0, ctx->stream, c, Op::src(args), qp);
           ctx->qposValid = true;
+        }
+        if (ctx->splitBuild == 8) {  // the op rides on the build
+          // (staging depth 32 and four survivors per drain trip: measured best of 16 / 24 / 32 x 2 / 4 / 6 / 8)
+          hipLaunchKernelGGL((k_build_lists_op<N, Op, 4, 32, 4>), g, b, 0, ctx->stream, c, args, Op::src(args), qp, args.type, key, table, nl, nc);
+          LAUNCH_CHECK(ctx);
+          return PBF_OK;
         }
         StageTimer tb(ctx, ST_BUILD);
         if (ctx->splitBuild == 4)

@@ -1439,6 +1439,120 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const 
   nbrCount[i] = written <= NBR_CAP ? written : NBR_OVERFLOW;
 }
 
+// The same build with an op riding on it (option split_build = 8): the survivors staged in LDS are not only flushed to
+// their row but folded through the op's exact pair terms on the way — lambda needs no launch and no list read of its own,
+// and its arithmetic runs in the issue slots the build (bound by the texture-address path, 4 waves per SIMD by its LDS)
+// leaves idle.  Same candidates in the same order as the list-driven reader: the same bits.
+template <typename N, typename Op, int W, int LMAX = 32, int FW = 4>
+__global__ __launch_bounds__(BLOCK) void k_build_lists_op(StepConsts<N> c, typename Op::Args args, const vec4<N> *__restrict__ pstar,
+                                                         const uint2 *__restrict__ qpos,
+                                                         const uint8_t *__restrict__ type,
+                                                         const uint32_t *__restrict__ key,
+                                                         const uint32_t *__restrict__ table,
+                                                         uint32_t *__restrict__ nbrList,
+                                                         uint32_t *__restrict__ nbrCount) {
+  static_assert(4 * W + 2 <= QPOS_PAD, "qpos padding");
+  __shared__ uint32_t list[(LMAX + 2 * W) * BLOCK];  // per-lane staging: a trip appends up to 2 W past LMAX - 1
+  const uint32_t tid = threadIdx.x;
+  const uint32_t chunk = xcd_chunk();
+  const uint32_t i = chunk * BLOCK + tid;
+  if (i >= c.n) return;
+  Op op;
+  if (!op.begin(c, args, i)) {  // (obstacles, ghosts: the op has stored what it owes them)
+    nbrCount[i] = 0;
+    return;
+  }
+  // 32-bit byte offsets from uniform bases: one shift per address
+  const char *qbase = reinterpret_cast<const char *>(qpos), *tbase = reinterpret_cast<const char *>(table);
+  bool usable;
+  const uint2 qa = quantise_position<N>(c, pstar[i], &usable);
+  const qpair axy = __builtin_bit_cast(qpair, qa.x), azw = __builtin_bit_cast(qpair, qa.y);
+  const uint32_t t2 = usable ? QPOS_T * QPOS_T : 0xFFFFFFFFu;
+  auto within = [&](uint32_t qx, uint32_t qy) {
+    const qpair dxy = __builtin_bit_cast(qpair, qx) - axy, dzw = __builtin_bit_cast(qpair, qy) - azw;
+    return uint32_t(qdot2(__builtin_bit_cast(uint32_t, dzw), qdot2(__builtin_bit_cast(uint32_t, dxy)))) <= t2;
+  };
+  uint32_t *blk = nbrList + size_t(chunk) * NBR_CAP * BLOCK;
+  uint32_t written = 0, nl = 0;
+  auto flush = [&]() {
+    for (uint32_t q = 0; __any(q < nl); q += FW) {  // FW survivors per trip: their gathers and pair terms interleave
+      uint32_t b[FW];
+      typename Op::Src cnd[FW];
+#pragma unroll
+      for (uint32_t w = 0; w < FW; ++w) b[w] = q + w < nl ? list[(q + w) * BLOCK + tid] : i;
+#pragma unroll
+      for (uint32_t w = 0; w < FW; ++w) cnd[w] = Op::load(args, b[w]);
+#pragma unroll
+      for (uint32_t w = 0; w < FW; ++w)
+        if (q + w < nl && written + q + w < NBR_CAP) blk[(written + q + w) * BLOCK + tid] = b[w];
+#pragma unroll
+      for (uint32_t w = 0; w < FW; ++w) op.add_bf(c, cnd[w], q + w < nl);
+    }
+    written += nl;
+    nl = 0;
+  };
+  // A (dy, dz) row of three x cells is TWO runs of the sorted array: the cells (2m, 2m + 1) have
+  // adjacent codes, so for an odd own x the row is [x-1, x] + [x+1], for an even one [x-1] + [x, x+1].
+  // Two loads per row: table[pair .. pair + 2] and table[single .. single + 1] (the table keeps entries
+  // up to tableN + 1).  A cell outside the table, and the table's last cell, are empty (sph.hpp:206-208).
+  const uint32_t k0 = key[i];
+  const Neigh nb = neigh_codes(k0);
+  const bool odd = (k0 & 1u) != 0u;
+  const uint32_t xPair = odd ? nb.xs[0] : nb.xs[1], xSingle = odd ? nb.xs[2] : nb.xs[0];
+  struct Row {
+    uint32_t sA, lA, sB, lB;
+  };
+  auto load_row = [&](int r) {
+    const uint32_t yz = nb.ys[r % 3] | nb.zs[r / 3];
+    const uint32_t cP = xPair | yz, cS = xSingle | yz;
+    const TableTriple tp = *reinterpret_cast<const TableTriple *>(tbase + min(cP, c.tableN) * 4u);
+    const TablePair ts = *reinterpret_cast<const TablePair *>(tbase + min(cS, c.tableN) * 4u);
+    const uint32_t lP0 = (cP + 1u) < c.tableN ? tp.t1 - tp.t0 : 0u, lP1 = (cP + 2u) < c.tableN ? tp.t2 - tp.t1 : 0u;
+    const uint32_t sP = lP0 ? tp.t0 : tp.t1, lP = lP0 + lP1;
+    const uint32_t lS = (cS + 1u) < c.tableN ? ts.t1 - ts.t0 : 0u;
+    Row row;
+    row.sA = odd ? sP : ts.t0, row.lA = odd ? lP : lS;
+    row.sB = odd ? ts.t0 : sP, row.lB = odd ? lS : lP;
+    return row;
+  };
+  Row next = load_row(0);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const Row row = next;
+    if (r < 8) next = load_row(r + 1);
+    // One slot sequence for the row, walked in PAIRS (slot 2j, 2j + 1 -> one 16-byte load): run A is
+    // padded to an even length so that no pair straddles the two runs; the pad slot is masked.
+    const uint32_t lA = row.lA, lAe = (lA + 1u) & ~1u, L = lAe + row.lB, oB = row.sB - lAe;
+    for (uint32_t t = 0; __any(t < L); t += 2 * W) {
+      if (t < L) {
+        uint32_t b[W], lim[W];
+        QPair cnd[W];
+#pragma unroll
+        for (uint32_t w = 0; w < W; ++w) {
+          const uint32_t sl = t + 2 * w;  // slots past L read what follows run B (QPOS_PAD) and are masked
+          const bool inA = sl < lAe;
+          b[w] = sl + (inA ? row.sA : oB);
+          lim[w] = inA ? lA : L;
+          cnd[w] = *reinterpret_cast<const QPair *>(qbase + b[w] * 8u);
+        }
+#pragma unroll
+        for (uint32_t w = 0; w < W; ++w) {
+          const bool hit0 = (t + 2 * w < lim[w]) & within(cnd[w].ax, cnd[w].ay);
+          list[nl * BLOCK + tid] = b[w];  // branch-free append: the slot is kept only on a hit
+          nl += hit0 ? 1u : 0u;
+          const bool hit1 = (t + 2 * w + 1 < lim[w]) & within(cnd[w].bx, cnd[w].by);
+          list[nl * BLOCK + tid] = b[w] + 1u;
+          nl += hit1 ? 1u : 0u;
+        }
+      }
+      if (__any(nl >= uint32_t(LMAX))) flush();
+    }
+  }
+  flush();
+  nbrCount[i] = written <= NBR_CAP ? written : NBR_OVERFLOW;
+  op.end(c, args, i);
+}
+
 // Pins a just-loaded candidate into registers at this point of the program.  Without it LLVM folds the loop-carried
 // phi(load in the prologue, load in the loop) back into ONE load at the loop head (InstCombine's phi-of-loads), which
 // silently un-pipelines k_gather_from_lists: the pair terms would again wait for gathers issued in the same trip.

@@ -36,7 +36,7 @@ def by_id(d):
 
 
 def mk(pkg, oracle, scene, fp64, flags=0, device_pow=True, gather=None):
-    """gather=None leaves the PRODUCT DEFAULT (filtered lists, split_build 5, cell_diffuse 1); a variant is
+    """gather=None leaves the PRODUCT DEFAULT (filtered lists, split_build 8, cell_diffuse 1); a variant is
     only selected where a test names it."""
     s = pkg.Solver(h=0.1, fp64=fp64, flags=flags)
     if gather is not None:
@@ -139,10 +139,11 @@ def test_free_running_bit_exact(pkg, oracle, scene, fp64, variant):
             assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
 
 
-@pytest.mark.parametrize("split,fp64", [(0, False), (4, False), (5, False), (0, True), (5, True)])
+@pytest.mark.parametrize("split,fp64", [(0, False), (4, False), (5, False), (8, False), (0, True), (5, True), (8, True)])
 def test_split_build_bit_exact(pkg, oracle, split, fp64):
     """Option split_build: 0 = lambda builds the neighbour lists while it gathers; 4 / 5 = a list-build launch of
-    its own (k_build_lists_q, 2 / 4 pair loads per trip) followed by a list-driven lambda.  Same
+    its own (k_build_lists_q, 2 / 4 pair loads per trip) followed by a list-driven lambda; 8 (default) = the quantised
+    build with lambda riding on its flushes (k_build_lists_op).  Same
     candidates in the same order either way — identical bits, obstacles and overflow rows included."""
     sc, side = get_scene(pkg, "dam8192", fp64)
     sc = {k: v.copy() for k, v in sc.items()}
@@ -508,8 +509,14 @@ def test_stage_timing(pkg):
     # "stage/part" entries are single kernels inside a stage (the neighbour-list build of the lambda stage)
     assert {k for k in t if "/" not in k} == stages and set(t) - stages == {"sph-lambda/list-build"}
     assert t["sph-lambda"][1] == 12 and t["sph-delta"][1] == 12 and t["advect+zindex"][1] == 3
+    # default (split_build 8): the list build and lambda are ONE kernel, the part entry stays empty
+    assert t["sph-lambda/list-build"][1] == 0
+    assert all(ms > 0 for k, (ms, _) in t.items() if "/" not in k)
+    s.set_option("split_build", 5)  # the build as a launch of its own: timed as a part of the lambda stage
+    s.reset_stage_times()
+    s.steps(p, 3)
+    t = s.stage_times()
     assert t["sph-lambda/list-build"][1] == 12 and 0 < t["sph-lambda/list-build"][0] < t["sph-lambda"][0]
-    assert all(ms > 0 for ms, _ in t.values())
 
 
 @pytest.mark.parametrize("nominal,fp64", [(262144, False), (1048576, False), (1048576, True), (4194304, False)])
