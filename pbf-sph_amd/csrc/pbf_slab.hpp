@@ -94,36 +94,49 @@ __global__ __launch_bounds__(BLOCK) void k_sel_scan(uint32_t nb, uint32_t *__res
   }
 }
 
-// pass 3: emit in array order
+// pass 3: emit in array order.  A wave takes 64 x SEL_ITEMS consecutive particles of the workgroup's tile in SEL_ITEMS
+// rounds of 64 (lane = particle: every load and, but for the holes, every store of a round is one contiguous run — a
+// thread per SEL_ITEMS consecutive particles, as the count pass has it, reads 16-byte records at a 64-byte stride); the
+// position inside a round is the ballot prefix, the wave's start inside the tile comes from a first sweep over keys and
+// types, the tile's start from pass 2.  Same order as the count pass: array order.
 template <typename N, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_sel_emit(uint32_t n, SlabCut s, ParticleArrays<N> src, ParticleArrays<N> dst,
                                                     uint32_t nb, const uint32_t *__restrict__ bases, void *sendL,
                                                     void *sendR, uint32_t capRecords, uint32_t *__restrict__ srcL,
                                                     uint32_t *__restrict__ srcR) {
-  const uint32_t base = blockIdx.x * SEL_TILE + threadIdx.x * SEL_ITEMS;
+  __shared__ uint32_t waveTot[3][BLOCK / 64];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t waveBase = blockIdx.x * SEL_TILE + wave * 64u * SEL_ITEMS;
+  const uint64_t below = (1ull << lane) - 1ull;
   uint32_t m[SEL_ITEMS];
-  uint32_t c0 = 0, c1 = 0, c2 = 0;
+  uint32_t t0 = 0, t1 = 0, t2 = 0;  // the wave's class totals (uniform)
 #pragma unroll
   for (int j = 0; j < SEL_ITEMS; ++j) {
-    const uint32_t i = base + j;
+    const uint32_t i = waveBase + j * 64u + lane;
     m[j] = i < n ? slab_classes<MODE>(src.key[i], src.type[i], s) : 0u;
-    c0 += m[j] & 1u, c1 += (m[j] >> 1) & 1u, c2 += (m[j] >> 2) & 1u;
+    t0 += uint32_t(__builtin_popcountll(__ballot((m[j] & 1u) != 0u)));
+    t1 += uint32_t(__builtin_popcountll(__ballot((m[j] & 2u) != 0u)));
+    t2 += uint32_t(__builtin_popcountll(__ballot((m[j] & 4u) != 0u)));
   }
-  uint32_t t;
-  uint32_t p0 = block_excl_scan(c0, &t) + bases[blockIdx.x];
-  uint32_t p1 = block_excl_scan(c1, &t) + bases[nb + blockIdx.x];
-  uint32_t p2 = block_excl_scan(c2, &t) + bases[2 * nb + blockIdx.x];
+  if (lane == 0) waveTot[0][wave] = t0, waveTot[1][wave] = t1, waveTot[2][wave] = t2;
+  __syncthreads();
+  uint32_t p0 = bases[blockIdx.x], p1 = bases[nb + blockIdx.x], p2 = bases[2 * nb + blockIdx.x];
+  for (uint32_t w = 0; w < wave; ++w) p0 += waveTot[0][w], p1 += waveTot[1][w], p2 += waveTot[2][w];
 #pragma unroll
   for (int j = 0; j < SEL_ITEMS; ++j) {
-    const uint32_t i = base + j;
+    const uint32_t i = waveBase + j * 64u + lane;
+    const uint64_t b0 = __ballot((m[j] & 1u) != 0u), b1 = __ballot((m[j] & 2u) != 0u), b2 = __ballot((m[j] & 4u) != 0u);
+    const uint32_t r0 = p0 + uint32_t(__builtin_popcountll(b0 & below)), r1 = p1 + uint32_t(__builtin_popcountll(b1 & below)),
+                   r2 = p2 + uint32_t(__builtin_popcountll(b2 & below));
+    p0 += uint32_t(__builtin_popcountll(b0)), p1 += uint32_t(__builtin_popcountll(b1)), p2 += uint32_t(__builtin_popcountll(b2));
     if (MODE == SEL_MIGRATE) {
       if (m[j] & 1u) {  // stays: stable compaction into the other array set
-        const uint32_t d = p0++;
+        const uint32_t d = r0;
         dst.pos4[d] = src.pos4[i], dst.vel4[d] = src.vel4[i], dst.col4[d] = src.col4[i], dst.pstar[d] = src.pstar[i];
         dst.id[d] = src.id[i], dst.type[d] = src.type[i], dst.key[d] = src.key[i];
       } else if (m[j] & 6u) {
         const bool left = (m[j] & 2u) != 0;
-        const uint32_t d = left ? p1++ : p2++;
+        const uint32_t d = left ? r1 : r2;
         if (d < capRecords) {
           MigrantRec<N> r;
           r.pos4 = src.pos4[i], r.vel4 = src.vel4[i], r.col4 = src.col4[i], r.pstar = src.pstar[i];
@@ -133,7 +146,7 @@ __global__ __launch_bounds__(BLOCK) void k_sel_emit(uint32_t n, SlabCut s, Parti
       }
     } else {
       if (m[j] & 1u) {
-        const uint32_t d = p0++;
+        const uint32_t d = r0;
         if (d < capRecords) {
           GhostRec<N> r;
           r.pstar = src.pstar[i], r.col4 = src.col4[i], r.key = src.key[i], r.type = src.type[i] | TYPE_GHOST;
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(BLOCK) void k_sel_emit(uint32_t n, SlabCut s, Parti
         }
       }
       if (m[j] & 2u) {
-        const uint32_t d = p1++;
+        const uint32_t d = r1;
         if (d < capRecords) {
           GhostRec<N> r;
           r.pstar = src.pstar[i], r.col4 = src.col4[i], r.key = src.key[i], r.type = src.type[i] | TYPE_GHOST;
