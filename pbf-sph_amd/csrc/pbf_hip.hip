@@ -1670,17 +1670,15 @@ int assembly_round(pbf_ctx *ctx, uint32_t chunk, size_t recBytes, int idxL, int 
   if (ctx->n == 0) HIPCHK(ctx, hipMemsetAsync(ctx->selTotals.p, 0, 16, ctx->stream));
   if (int rc = run_select<N, MODE>(ctx, &cut, sL + WIRE_HDR, sR + WIRE_HDR, ctx->wireCap, t, false)) return rc;
   hipLaunchKernelGGL(k_wire_headers, dim3(1), dim3(64), 0, ctx->stream, ctx->selTotals.as<const uint32_t>(), idxL, idxR,
-                     reinterpret_cast<uint32_t *>(sL), reinterpret_cast<uint32_t *>(sR));
+                     reinterpret_cast<uint32_t *>(sL), reinterpret_cast<uint32_t *>(sR), reinterpret_cast<uint32_t *>(rL),
+                     reinterpret_cast<uint32_t *>(rR));
   LAUNCH_CHECK(ctx);
   const size_t first = WIRE_HDR + size_t(chunk) * recBytes;
-  // a rank without that neighbour neither sends nor receives on that side: its header reads 0
-  HIPCHK(ctx, hipMemsetAsync(rL, 0, WIRE_HDR, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(rR, 0, WIRE_HDR, ctx->stream));
   if (int rc = exchange(ctx, first, first, first, first)) return rc;
-  uint32_t *h = ctx->hostCounts;
-  HIPCHK(ctx, hipMemcpyAsync(h, ctx->selTotals.p, 12, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(h + 4, rL, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(h + 5, rR, 4, hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t *h = ctx->hostCounts;  // pinned, device-visible: the kernel writes the six words itself
+  hipLaunchKernelGGL(k_wire_counts, dim3(1), dim3(64), 0, ctx->stream, ctx->selTotals.as<const uint32_t>(),
+                     reinterpret_cast<const uint32_t *>(rL), reinterpret_cast<const uint32_t *>(rR), h);
+  LAUNCH_CHECK(ctx);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the one read-back of this round: counts size the launches below
   own[0] = h[0], own[1] = h[1], own[2] = h[2];
   got[0] = h[4], got[1] = h[5];

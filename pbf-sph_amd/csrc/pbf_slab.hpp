@@ -173,10 +173,23 @@ __global__ __launch_bounds__(BLOCK) void k_sel_emit(uint32_t n, SlabCut s, Parti
 // array}; the counts never travel on their own.
 constexpr size_t WIRE_HDR = 32;  // keeps the records 32-byte aligned (double4)
 __global__ void k_wire_headers(const uint32_t *__restrict__ totals, int idxL, int idxR, uint32_t *__restrict__ hdrL,
-                               uint32_t *__restrict__ hdrR) {
+                               uint32_t *__restrict__ hdrR, uint32_t *__restrict__ recvL, uint32_t *__restrict__ recvR) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     hdrL[0] = totals[idxL];
     hdrR[0] = totals[idxR];
+  }
+  // a rank without that neighbour neither sends nor receives on that side: its incoming header reads 0
+  if (blockIdx.x == 0 && threadIdx.x < WIRE_HDR / 4) recvL[threadIdx.x] = 0u, recvR[threadIdx.x] = 0u;
+}
+
+// After the exchange: {own totals[3], -, count from the left, count from the right} straight into the caller's pinned
+// host words (one launch instead of three small copies)
+__global__ void k_wire_counts(const uint32_t *__restrict__ totals, const uint32_t *__restrict__ recvL,
+                              const uint32_t *__restrict__ recvR, uint32_t *__restrict__ host) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    host[0] = totals[0], host[1] = totals[1], host[2] = totals[2];
+    host[4] = recvL[0], host[5] = recvR[0];
+    __threadfence_system();
   }
 }
 
@@ -216,7 +229,9 @@ __global__ __launch_bounds__(BLOCK) void k_append_ghosts(uint32_t at, const Ghos
 __global__ __launch_bounds__(BLOCK) void k_count_keys(uint32_t n, uint32_t tableN, const uint32_t *__restrict__ key,
                                                       uint32_t *__restrict__ count) {
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i < n) atomicAdd(&count[min(key[i], tableN)], 1u);
+  if (i >= n) return;
+  uint32_t before, rank;  // one atomic per distinct cell per wave (the keeps are still in Z order)
+  wave_bucket_atomic(min(key[i], tableN), [&](uint32_t b, uint32_t cnt) { return atomicAdd(&count[b], cnt); }, before, rank);
 }
 
 // owned particles per GLOBAL grid column (1024 bins, LDS-privatised): the load-balance input of the slab driver
