@@ -147,6 +147,7 @@ struct pbf_ctx {
                              // fp64 only (measured at 1 M: fp64 -1.3 %, fp32 +3 % — fp32's readers are VALU-issue bound)
   int coop = 0;              // option "coop": 0 = one lane per particle (bit-exact), 2 / 4 / 8 = lanes sharing a particle's
                              // list with a wave-shuffle reduction (k_gather_from_lists_coop; rounding-level differences)
+  bool fusePredict = true;   // option "fuse_predict": pbf_steps runs finalise(t) + predict(t + 1) as one kernel
   bool cellDiffuse = true;   // option "cell_diffuse": one walk per occupied cell instead of one per particle
   // option "overlap_diffuse" (default on): inside pbf_step the colour diffusion — memory-latency bound, 85 % of its wave
   // time parked — runs on a side stream beside the VALU-bound solver iterations (nothing else touches colours)
@@ -158,6 +159,8 @@ struct pbf_ctx {
   bool fuseDiffuse = false;  // option "fuse_diffuse": pbf_step folds the diffuse walk into the first lambda launch
                              // (bit-identical; measured 2 % SLOWER at 1 M — the colour loads stall the filter loop — so off)
   bool fuseDiffuseNow = false;
+  // pbf_steps: the NEXT step's predict rides on this step's finalise (k_finalise_predict) / has already been done
+  bool fuseNextPredict = false, prePredicted = false;
   DevBuf bricks, brickCtl;  // non-empty brick list; brickCtl = {nActive, ticket[kTickets], nBigCells}
   DevBuf bigCells;          // cells with more than BIG_CELL members this step (k_sort_big_cells)
   uint32_t gatherSeq = 0;   // which ticket word the next persistent gather launch uses
@@ -791,8 +794,31 @@ template <typename N> int extras(pbf_ctx *ctx, const pbf_params *p, const StepCo
 template <typename N> int stage_finalise(pbf_ctx *ctx, const pbf_params *p) {
   StepConsts<N> c;
   if (int rc = make_consts<N>(ctx, p, c)) return rc;
-  StageTimer t(ctx, ST_FINALISE);
   const int s = ctx->cur;
+  if (ctx->fuseNextPredict && !(p->vorticity || p->xsph)) {
+    // finalise(t) + predict(t + 1) in one pass: everything stage_predict does, around one launch
+    ctx->fuseNextPredict = false;
+    if (int rc = ensure_table(ctx, c.tableN)) return rc;
+    if (int rc = drop_histogram(ctx)) return rc;
+    if (int rc = upload_wells(ctx, p)) return rc;
+    if (int rc = join_diffuse(ctx)) return rc;  // (the side stream reads keys and types of this step)
+    StageTimer t(ctx, ST_FINALISE);
+    if (ctx->pcur != s) {  // pStar is overwritten in place: make the live buffer pstar[cur] first
+      std::swap(ctx->pstar[ctx->pcur], ctx->pstar[s]);
+      ctx->pcur = s;
+    }
+    hipLaunchKernelGGL((k_finalise_predict<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c,
+                       ctx->type[s].as<const uint8_t>(), ctx->pstar[s].as<vec4<N>>(), ctx->pos4[s].as<vec4<N>>(),
+                       ctx->vel4[s].as<vec4<N>>(), ctx->wells.as<const N>(), ctx->key[s].as<uint32_t>(),
+                       ctx->count.as<uint32_t>());
+    LAUNCH_CHECK(ctx);
+    ctx->sorted = false, ctx->nbrValid = false, ctx->qposValid = false;
+    ctx->counted = true, ctx->countedTableN = c.tableN;
+    ctx->prePredicted = true;
+    return PBF_OK;
+  }
+  ctx->fuseNextPredict = false;
+  StageTimer t(ctx, ST_FINALISE);
   hipLaunchKernelGGL((k_finalise<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c,
                      ctx->type[s].as<const uint8_t>(), ctx->pstar[ctx->pcur].as<const vec4<N>>(),
                      ctx->pos4[s].as<vec4<N>>(), ctx->vel4[s].as<vec4<N>>());
@@ -809,7 +835,11 @@ template <typename N> int stage_finalise(pbf_ctx *ctx, const pbf_params *p) {
 
 template <typename N> int step_impl(pbf_ctx *ctx, const pbf_params *p) {
   if (ctx->n == 0) return PBF_OK;  // "Particles depleted" (ompsph.hpp:122-126)
-  if (int rc = stage_predict<N>(ctx, p)) return rc;
+  if (ctx->prePredicted) {
+    ctx->prePredicted = false;  // the previous step of this pbf_steps call has predicted already (k_finalise_predict)
+  } else if (int rc = stage_predict<N>(ctx, p)) {
+    return rc;
+  }
   if (int rc = stage_sort<N>(ctx, p)) return rc;
   // diffuse (ompsph.hpp:188-207) visits exactly the candidates of the first lambda launch: fuse the two walks
   const bool fuse = ctx->fuseDiffuse && p->iteration > 0 && ctx->gatherKind == 1 && ctx->reuseLists &&
@@ -845,7 +875,7 @@ int upload_impl(pbf_ctx *ctx, size_t n, const uint64_t *id, const uint8_t *type,
   if (int rc = ensure_particles(ctx, n)) return rc;
   if (int rc = drop_histogram(ctx)) return rc;
   ctx->cur = 0, ctx->pcur = 0, ctx->sorted = false;
-  ctx->ghostsPending = false, ctx->slabActive = false;
+  ctx->ghostsPending = false, ctx->slabActive = false, ctx->prePredicted = false;
   ctx->n = n;
   ctx->hasObstacles = false;
   if (n == 0) return PBF_OK;
@@ -920,6 +950,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
     ctx->coop = int(value);
   }
   else if (n == "split_build") ctx->splitBuild = int(value);
+  else if (n == "fuse_predict") ctx->fusePredict = value != 0;
   else if (n == "timing_mask") ctx->timingMask = uint32_t(value);
   else if (n == "pad_lds") ctx->padLds = uint32_t(value);
   else return fail(ctx, PBF_ERR_INVALID, "unknown option " + n);
@@ -1257,8 +1288,19 @@ int step_maybe_graphed(pbf_ctx *ctx, const pbf_params *p) {
 int pbf_steps(pbf_ctx *ctx, const pbf_params *p, uint32_t count) {
   if (int rc = check(ctx, p, false)) return rc;
   if (int rc = drop_ghosts(ctx)) return rc;
-  for (uint32_t i = 0; i < count; ++i)
-    if (int rc = step_maybe_graphed(ctx, p)) return rc;
+  // finalise(t) + predict(t + 1) as one kernel between two steps of THIS call (same parameters, nothing observes the
+  // state in between).  Not with stage timing on either entry, hipGraph replay, slabs or a step that may stop early.
+  const bool timed = (ctx->desc.flags & PBF_FLAG_STAGE_TIMING) != 0 &&
+                     (((ctx->timingMask >> ST_PREDICT) & 1u) != 0 || ((ctx->timingMask >> ST_FINALISE) & 1u) != 0);
+  const bool fusable = ctx->fusePredict && !timed && ctx->graphMode <= 0 && !ctx->slabActive && ctx->n != 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    ctx->fuseNextPredict = fusable && i + 1 < count;
+    if (int rc = step_maybe_graphed(ctx, p)) {
+      ctx->fuseNextPredict = ctx->prePredicted = false;
+      return rc;
+    }
+  }
+  ctx->fuseNextPredict = false;
   return PBF_OK;
 }
 int pbf_graph_stats(const pbf_ctx *ctx, uint64_t out[3]) {

@@ -50,17 +50,12 @@ template <typename F> __device__ inline void wave_bucket_atomic(uint32_t bucket,
   before = __shfl(v, int(leader), 64);
 }
 
+// predict + key of one particle (reference: ompsph.hpp:137-154): updates v, returns pStar, writes the key
 template <typename N>
-__global__ __launch_bounds__(BLOCK) void k_predict(StepConsts<N> c, const vec4<N> *__restrict__ pos4,
-                                                   vec4<N> *__restrict__ vel4, const uint8_t *__restrict__ type,
-                                                   const N *__restrict__ wells, vec4<N> *__restrict__ pstar,
-                                                   uint32_t *__restrict__ key, uint32_t *__restrict__ count) {
-  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= c.n) return;
-  const vec4<N> p = pos4[i];
-  vec4<N> v = vel4[i];
+__device__ inline vec4<N> predict_one(const StepConsts<N> &c, const vec4<N> &p, vec4<N> &v, uint8_t type,
+                                      const N *__restrict__ wells, uint32_t &k) {
   N px, py, pz;
-  if (c.hasObstacles && (type[i] & 1)) {
+  if (c.hasObstacles && (type & 1)) {
     px = p.x / c.scale, py = p.y / c.scale, pz = p.z / c.scale;
   } else {
     const N mass = p.w;
@@ -81,15 +76,29 @@ __global__ __launch_bounds__(BLOCK) void k_predict(StepConsts<N> c, const vec4<N
       }
     }
     v.x = fx * c.dt + v.x, v.y = fy * c.dt + v.y, v.z = fz * c.dt + v.z;
-    vel4[i] = v;
     px = (v.x * c.dt) + (p.x / c.scale);
     py = (v.y * c.dt) + (p.y / c.scale);
     pz = (v.z * c.dt) + (p.z / c.scale);
   }
-  pstar[i] = make_vec4<N>(px, py, pz, N(0));
-  const uint32_t k = morton_encode(static_cast<uint32_t>(cell_coord((px - c.minExtent[0]) / c.h)) - c.xoff,
-                                   static_cast<uint32_t>(cell_coord((py - c.minExtent[1]) / c.h)),
-                                   static_cast<uint32_t>(cell_coord((pz - c.minExtent[2]) / c.h)));
+  k = morton_encode(static_cast<uint32_t>(cell_coord((px - c.minExtent[0]) / c.h)) - c.xoff,
+                    static_cast<uint32_t>(cell_coord((py - c.minExtent[1]) / c.h)),
+                    static_cast<uint32_t>(cell_coord((pz - c.minExtent[2]) / c.h)));
+  return make_vec4<N>(px, py, pz, N(0));
+}
+
+template <typename N>
+__global__ __launch_bounds__(BLOCK) void k_predict(StepConsts<N> c, const vec4<N> *__restrict__ pos4,
+                                                   vec4<N> *__restrict__ vel4, const uint8_t *__restrict__ type,
+                                                   const N *__restrict__ wells, vec4<N> *__restrict__ pstar,
+                                                   uint32_t *__restrict__ key, uint32_t *__restrict__ count) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= c.n) return;
+  const vec4<N> p = pos4[i];
+  vec4<N> v = vel4[i];
+  const uint8_t ty = c.hasObstacles ? type[i] : uint8_t(0);
+  uint32_t k;
+  pstar[i] = predict_one<N>(c, p, v, ty, wells, k);
+  if (!(c.hasObstacles && (ty & 1))) vel4[i] = v;
   key[i] = k;
   // bucket tableN collects particles outside the table: they are "in no cell" (sph.hpp:206)
   uint32_t before, rank;
@@ -1679,6 +1688,13 @@ __global__ __launch_bounds__(BLOCK) void k_gather_from_lists_coop(StepConsts<N> 
 // ------------------------------------------------------------------------------------------------
 // finalise (ompsph.hpp:256-264): pure stream, 48 B in / 32 B out per particle (fp32)
 // ------------------------------------------------------------------------------------------------
+template <typename N> __device__ inline void finalise_one(const StepConsts<N> &c, const vec4<N> &ps, vec4<N> &p, vec4<N> &v) {
+  const N dxx = ps.x - p.x / c.scale, dyy = ps.y - p.y / c.scale, dzz = ps.z - p.z / c.scale;
+  const N invdt = N(1) / c.dt;
+  p.x = ps.x * c.scale, p.y = ps.y * c.scale, p.z = ps.z * c.scale;
+  v.x = (dxx * invdt + v.x) * N(VD), v.y = (dyy * invdt + v.y) * N(VD), v.z = (dzz * invdt + v.z) * N(VD);
+}
+
 template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_finalise(StepConsts<N> c, const uint8_t *__restrict__ type,
                                                     const vec4<N> *__restrict__ pstar, vec4<N> *__restrict__ pos4,
@@ -1686,15 +1702,35 @@ __global__ __launch_bounds__(BLOCK) void k_finalise(StepConsts<N> c, const uint8
   const uint32_t a = blockIdx.x * BLOCK + threadIdx.x;
   if (a >= c.n) return;
   if (c.hasObstacles && type[a] != 0) return;  // obstacles and ghosts do not move here
-  const vec4<N> ps = pstar[a];
-  vec4<N> p = pos4[a];
-  vec4<N> v = vel4[a];
-  const N dxx = ps.x - p.x / c.scale, dyy = ps.y - p.y / c.scale, dzz = ps.z - p.z / c.scale;
-  const N invdt = N(1) / c.dt;
-  p.x = ps.x * c.scale, p.y = ps.y * c.scale, p.z = ps.z * c.scale;
-  v.x = (dxx * invdt + v.x) * N(VD), v.y = (dyy * invdt + v.y) * N(VD), v.z = (dzz * invdt + v.z) * N(VD);
+  vec4<N> p = pos4[a], v = vel4[a];
+  finalise_one<N>(c, pstar[a], p, v);
   pos4[a] = p;
   vel4[a] = v;
+}
+
+// finalise(t) and predict(t + 1) of one particle in one pass (pbf_steps, same parameters for both steps, nothing between
+// them): the finalised position and velocity stay in registers, pStar is overwritten in place by the next prediction —
+// one launch and 48 bytes per particle of re-reads less.  `cn` carries step t + 1's constants (the same, but for the
+// frame-dependent ones a caller may have changed — the host only fuses when they are equal).
+template <typename N>
+__global__ __launch_bounds__(BLOCK) void k_finalise_predict(StepConsts<N> c, const uint8_t *__restrict__ type,
+                                                            vec4<N> *__restrict__ pstar, vec4<N> *__restrict__ pos4,
+                                                            vec4<N> *__restrict__ vel4, const N *__restrict__ wells,
+                                                            uint32_t *__restrict__ key, uint32_t *__restrict__ count) {
+  const uint32_t a = blockIdx.x * BLOCK + threadIdx.x;
+  if (a >= c.n) return;
+  const uint8_t ty = c.hasObstacles ? type[a] : uint8_t(0);
+  vec4<N> p = pos4[a], v = vel4[a];
+  if (ty == 0) {
+    finalise_one<N>(c, pstar[a], p, v);
+    pos4[a] = p;
+  }
+  uint32_t k;
+  pstar[a] = predict_one<N>(c, p, v, ty, wells, k);
+  if (!(ty & 1)) vel4[a] = v;
+  key[a] = k;
+  uint32_t before, rank;
+  wave_bucket_atomic(min(k, c.tableN), [&](uint32_t b, uint32_t cnt) { return atomicAdd(&count[b], cnt); }, before, rank);
 }
 
 // ------------------------------------------------------------------------------------------------

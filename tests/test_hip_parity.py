@@ -636,6 +636,33 @@ def test_ranged_sqrt_and_divide_are_the_ieee_ones(pkg):
 
 
 @pytest.mark.parametrize("fp64", [False, True])
+def test_steps_fuses_finalise_and_predict_bit_exact(pkg, oracle, fp64):
+    """pbf_steps runs finalise(t) + predict(t + 1) as ONE kernel between two steps of a call (option fuse_predict,
+    default on; the last step of a call stays unfused, so the state a caller sees is the finalised one): same bits
+    as step-by-step calls and as the oracle — obstacles and a gravity well included."""
+    sc, side = get_scene(pkg, "dam8192", fp64)
+    sc = {k: v.copy() for k, v in sc.items()}
+    sc["type"][::17] = 1
+    p, q = params_pair(pkg, oracle, side=side, wells=[(0.5 * side, 0.4 * side, 0.5 * side, 900.0)])
+    a, o = mk(pkg, oracle, sc, fp64)          # fused: 3 calls of 4 steps
+    b = pkg.Solver(h=0.1, fp64=fp64)          # step by step
+    b.upload(**sc)
+    c = pkg.Solver(h=0.1, fp64=fp64)          # pbf_steps with the fusion off
+    c.upload(**sc)
+    c.set_option("fuse_predict", 0)
+    for chunk in range(3):
+        a.steps(p, 4)
+        c.steps(p, 4)
+        for _ in range(4):
+            b.step(p)
+            o.step(q)
+        ga, gb, gc = a.download(), b.download(), c.download()
+        for k in ga:
+            assert np.array_equal(ga[k], gb[k]) and np.array_equal(ga[k], gc[k]), (chunk, k)
+        assert_state_equal(ga, o.get_particles(), f"chunk {chunk}")
+
+
+@pytest.mark.parametrize("fp64", [False, True])
 def test_graph_replay_bit_exact(pkg, oracle, fp64):
     """pbf_steps can replay each distinct step as a captured hipGraph (option graph; off by default: measured slower than
     eager launches): the buffer roles rotate
