@@ -78,7 +78,7 @@ void pbf_destroy(pbf_ctx *ctx);
 /* ctx may be NULL: last error of a failed pbf_create on this thread */
 const char *pbf_last_error(const pbf_ctx *ctx);
 int pbf_abi_version(void);
-/* Tuning / diagnostic knobs (no reference counterpart): "gather" (0 global walk, 1 filtered lists, 2 LDS bricks),
+/* Tuning / diagnostic knobs (no reference counterpart): "gather" (0 global walk, 1 neighbour lists, 3 LDS tiles per brick),
  * "list_max", "tile_cap", "reuse_lists", "split_build" (0 lambda builds the lists itself, 4 / 5 list-build launch with 2 / 4 pair loads per trip,
  * default 5), "coop" (0 = one lane per particle in the list-driven lambda / delta-p, bit-exact, default; 2 / 4 / 8 = that many
  * lanes share a particle's list and reduce the kernel sums with wave shuffles: rounding-level differences),

@@ -167,7 +167,7 @@ struct pbf_ctx {
   int numCUs = 256;
   uint32_t timingMask = 0xFFFFFFFFu;  // option "timing_mask": which stages PBF_FLAG_STAGE_TIMING brackets with events
   uint32_t padLds = 0;      // option "pad_lds": occupancy limiter for k_gather_global
-  int gatherKind = 1;       // 0 = global walk (k_gather_global), 1 = filtered lists (default), 2 = persistent LDS bricks
+  int gatherKind = 1;       // 0 = global walk (k_gather_global), 1 = neighbour lists (default), 3 = LDS tiles per brick (pbf_tiles.hpp)
   uint32_t tileCap = 0, listMax = 0;  // 0 = defaults (env PBF_TILE_CAP / PBF_LIST_MAX override)
   size_t tableCap = 0;   // entries allocated in count/table
   uint32_t tableN = 0;
@@ -599,40 +599,7 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
     LAUNCH_CHECK(ctx);
     return PBF_OK;
   }
-  if constexpr (!Op::kTileable) {
-    hipLaunchKernelGGL((k_gather_global<N, Op>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, args, key, table);
-    LAUNCH_CHECK(ctx);
-    return PBF_OK;
-  } else {
-  constexpr int BZ = kBrickZ, THREADS = 256;
-  using B = Brick2<BZ>;
-  using Src = typename Op::Src;
-  // LDS per workgroup = header + tile[cap] + list[lmax][THREADS]; defaults give 2 workgroups per CU
-  // (tile sized for the 1.84x over-dense start lattice: 216 cells x 11.7) — see DESIGN.md
-  uint32_t cap = ctx->tileCap ? ctx->tileCap : (sizeof(Src) == 16 ? 3072u : 1536u);
-  uint32_t lmax = Op::kFilter ? (ctx->listMax ? std::max(ctx->listMax, 40u) : 56u) : 0u;
-  if (cap > 65535u) cap = 65535u;  // list entries are uint16 record indices
-  const size_t lds = B::HDR2 + size_t(cap) * sizeof(Src) + size_t(lmax) * THREADS * 2;
-  if (lds > 160 * 1024 - 64) return fail(ctx, PBF_ERR_INVALID, "tile cap / list max exceed the CU's 160 KiB LDS");
-  auto kernel = k_gather_bricks<N, Op, BZ, THREADS>;
-  static size_t attrSet = 0;  // per instantiation
-  if (lds > attrSet) {
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    int(lds)));
-    attrSet = lds;
-  }
-  const uint32_t perCU = uint32_t(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 64))));
-  if (ctx->gatherSeq >= kTickets) {  // more gather launches than tickets since the last sort: re-arm
-    HIPCHK(ctx, hipMemsetAsync(ctx->brickCtl.as<uint32_t>() + 1, 0, kTickets * 4, ctx->stream));
-    ctx->gatherSeq = 0;
-  }
-  uint32_t *ctl = ctx->brickCtl.as<uint32_t>();
-  hipLaunchKernelGGL(kernel, dim3(uint32_t(ctx->numCUs) * perCU), dim3(THREADS), lds, ctx->stream, c, args, key,
-                     table, ctx->bricks.as<const uint32_t>(), ctl, ctl + 1 + ctx->gatherSeq, cap, lmax);
-  ctx->gatherSeq++;
-  LAUNCH_CHECK(ctx);
-  return PBF_OK;
-  }
+  return fail(ctx, PBF_ERR_INVALID, "unknown gather kind");
 }
 
 // The overlapped diffusion must be done before anything rewrites what it reads (colours, types, keys, table, brick
@@ -937,7 +904,10 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   if (!ctx || !name) return PBF_ERR_INVALID;
   const std::string n(name);
   if (n == "list_max") ctx->listMax = uint32_t(value);
-  else if (n == "gather") ctx->gatherKind = int(value);
+  else if (n == "gather") {
+    if (value != 0 && value != 1 && value != 3) return fail(ctx, PBF_ERR_INVALID, "gather: 0, 1 or 3 (2, round 1's brick kernel, was removed)");
+    ctx->gatherKind = int(value);
+  }
   else if (n == "tile_cap") ctx->tileCap = uint32_t(value);
   else if (n == "reuse_lists") ctx->reuseLists = value != 0;
   else if (n == "fuse_diffuse") ctx->fuseDiffuse = value != 0;
@@ -998,7 +968,10 @@ int pbf_create(const pbf_desc *desc, pbf_ctx **out) {
   ctx->fast = (desc->flags & PBF_FLAG_FAST_MATH) != 0;
   ctx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = std::getenv("PBF_TILE_CAP")) ctx->tileCap = uint32_t(std::atoi(e));
-  if (const char *e = std::getenv("PBF_GATHER")) ctx->gatherKind = std::atoi(e);
+  if (const char *e = std::getenv("PBF_GATHER")) {
+    const int g = std::atoi(e);
+    if (g == 0 || g == 1 || g == 3) ctx->gatherKind = g;  // (2, round 1's brick kernel, was removed)
+  }
   if (const char *e = std::getenv("PBF_REUSE_LISTS")) ctx->reuseLists = std::atoi(e) != 0;
   if (const char *e = std::getenv("PBF_SPLIT_BUILD")) ctx->splitBuild = std::atoi(e);
   if (const char *e = std::getenv("PBF_LIST_MAX")) ctx->listMax = uint32_t(std::atoi(e));

@@ -877,24 +877,11 @@ __global__ __launch_bounds__(BLOCK) void k_gather_global(StepConsts<N> c, typena
 }
 
 // ------------------------------------------------------------------------------------------------
-// Gather kernel "bricks" (option gather = 2) — LDS bricks.  One workgroup owns a Morton-aligned brick of 4 x 4 x BZ cells:
-// 16*BZ consecutive Morton codes, i.e. ONE contiguous run of sorted particles.  It stages the
-// brick's 6 x 6 x (BZ+2) halo of cells into LDS once — cell start/end from the grid table, then the
-// candidates' 16-byte (fp32) records — laid out x-fastest, so that for any home cell the three
-// x-adjacent neighbour cells are one contiguous LDS run: a particle walks 9 runs instead of 27 cell
-// ranges, in exactly the reference's order (sph.hpp:220-234).  Each candidate record is fetched
-// from L2/HBM ~3.4x (BZ=4) per launch instead of ~180x through L1.  A brick whose halo holds more
-// than `cap` records (piles at walls) falls back to the global walk.
-//   * persistent workgroups pull bricks from a device-side list of NON-EMPTY bricks through an
-//     atomic ticket (k_brick_list builds the list during the sort stage), so the ~90 % of bricks
-//     that hold no fluid never cost a launch slot; the loop ends when the ticket passes the list
-//     end — every wave reaches that exit;
-//   * for lambda / delta each lane first FILTERS its ~100 candidates with the conservative
-//     maybe_within_h test (3 sub + 3 fma + cmp out of LDS) into a per-lane list of LDS record
-//     indices (uint16, laid out [slot][thread] so a wave's accesses are consecutive), then runs
-//     the exact pair terms only over the ~25 that survive, still in the reference's visiting order.
-//     Rejected candidates contribute exactly +0, so every result bit is unchanged.
-//   LDS: header (run offsets, global starts, ticket) | tile[cap] records | list[lmax][THREADS] u16
+// Morton bricks: a Morton-aligned brick of 4 x 4 x BZ cells is 16*BZ consecutive codes, i.e. ONE contiguous run of the
+// sorted particles; its 6 x 6 x (BZ+2) halo of cells, staged x-fastest, makes the three x cells of a (dy, dz) row one
+// contiguous run.  Used by the per-cell diffusion (k_diffuse_bricks) and the LDS-tile iteration kernels (pbf_tiles.hpp);
+// k_brick_list compiles the list of non-empty bricks during the sort stage.  (Round 1's k_gather_bricks — filter and
+// pair terms per launch out of such a tile, option gather = 2 — was removed in round 2: superseded by pbf_tiles.hpp.)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_brick_list(const uint32_t *__restrict__ table, uint32_t tableN,
                                                       uint32_t home, uint32_t nBricks,
@@ -917,120 +904,6 @@ template <int BZ> struct Brick2 : Brick<BZ> {
   static constexpr int HDR2 = ((2 * Brick<BZ>::HALO + 1 + 1) * 4 + 15) / 16 * 16;  // + the ticket word
 };
 
-template <typename N, typename Op, int BZ, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_gather_bricks(StepConsts<N> c, typename Op::Args args,
-                                                           const uint32_t *__restrict__ key,
-                                                           const uint32_t *__restrict__ table,
-                                                           const uint32_t *__restrict__ active,
-                                                           const uint32_t *__restrict__ nActivePtr,
-                                                           uint32_t *__restrict__ ticket, uint32_t cap,
-                                                           uint32_t lmax) {
-  using B = Brick2<BZ>;
-  using Src = typename Op::Src;
-  static_assert(B::HALO <= THREADS, "one halo cell per thread in phase 1/2");
-  extern __shared__ __align__(16) unsigned char smem[];
-  uint32_t *off = reinterpret_cast<uint32_t *>(smem);  // [HALO + 1]
-  uint32_t *gstart = off + B::HALO + 1;                // [HALO]
-  uint32_t *shTicket = gstart + B::HALO;               // [1]
-  Src *tile = reinterpret_cast<Src *>(smem + B::HDR2);
-  uint16_t *list = reinterpret_cast<uint16_t *>(smem + B::HDR2 + size_t(cap) * sizeof(Src));
-  const uint32_t tid = threadIdx.x;
-  const uint32_t nActive = *nActivePtr;
-  const Src *src = Op::src(args);
-  // the last workgroups also sweep the particles that lie in no cell (key >= tableN, sph.hpp:206)
-  {
-    const uint32_t stride = gridDim.x * THREADS;
-    for (uint32_t i = table[c.tableN] + blockIdx.x * THREADS + tid; i < c.n; i += stride)
-      gather_one_global<N, Op>(c, args, key, table, i);
-  }
-
-  for (;;) {
-    __syncthreads();  // previous brick's LDS reads are done before the header / tile are rewritten
-    if (tid == 0) *shTicket = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint32_t t = *shTicket;
-    if (t >= nActive) break;  // uniform: every wave of the workgroup leaves here
-    const uint32_t brick = active[t];
-    const uint32_t code0 = brick * B::HOME;
-    const uint32_t hs = table[code0];
-    const uint32_t he = table[min(code0 + uint32_t(B::HOME), c.tableN)];
-
-    // ---- phase 1: the halo's cell ranges and their exclusive scan ------------------------------
-    const uint32_t bx = compact10(code0), by = compact10(code0 >> 1), bz = compact10(code0 >> 2);
-    uint32_t cnt = 0;
-    if (tid < B::HALO) {
-      const uint32_t lx = tid % 6, ly = (tid / 6) % 6, lz = tid / 36;
-      const uint32_t code = morton_encode((bx + lx - 1u) & 1023u, (by + ly - 1u) & 1023u, (bz + lz - 1u) & 1023u);
-      uint32_t s = 0, e = 0;
-      if (code < c.tableN) {  // sph.hpp:206-208
-        s = table[code];
-        e = (code + 1u) < c.tableN ? table[code + 1u] : s;
-      }
-      gstart[tid] = s;
-      cnt = e - s;
-    }
-    uint32_t total;
-    const uint32_t ex = block_excl_scan<THREADS>(cnt, &total);
-    if (tid < B::HALO) off[tid] = ex;
-    if (tid == 0) off[B::HALO] = total;
-    __syncthreads();
-
-    const bool tiled = total <= cap && !(Op::kNeedsCandidateType && c.hasObstacles);
-    if (!tiled) {  // pile-up beyond the tile, or diffuse with obstacles: plain global walk
-      for (uint32_t i = hs + tid; i < he; i += THREADS) gather_one_global<N, Op>(c, args, key, table, i);
-      continue;
-    }
-    // ---- phase 2: stage the candidates ------------------------------------------------------------
-    if (tid < B::HALO) {
-      const uint32_t s = gstart[tid], o = off[tid];
-      for (uint32_t j = 0; j < cnt; ++j) tile[o + j] = src[s + j];
-    }
-    __syncthreads();
-    // ---- phase 3: every home particle walks its 9 x-runs out of LDS -------------------------------
-    for (uint32_t i = hs + tid; i < he; i += THREADS) {
-      Op op;
-      if (!op.begin(c, args, i)) continue;
-      const uint32_t k = key[i];
-      const uint32_t hx = (k & 1u) | ((k >> 2) & 2u);         // bits 0, 3
-      const uint32_t hy = ((k >> 1) & 1u) | ((k >> 3) & 2u);  // bits 1, 4
-      const uint32_t hz = BZ == 4 ? (((k >> 2) & 1u) | ((k >> 4) & 2u)) : ((k >> 2) & 1u);  // bits 2, (5)
-      if constexpr (Op::kFilter) {
-        uint32_t nl = 0;
-        auto flush = [&]() {
-          for (uint32_t q = 0; q < nl; ++q) op.add_bf(c, tile[list[q * THREADS + tid]]);
-          nl = 0;
-        };
-#pragma unroll 1
-        for (uint32_t dz = 0; dz < 3; ++dz)
-#pragma unroll 1
-          for (uint32_t dy = 0; dy < 3; ++dy) {
-            const uint32_t l0 = ((hz + dz) * 6u + (hy + dy)) * 6u + hx;
-            const uint32_t s = off[l0], e = off[l0 + 3];
-#pragma unroll 4
-            for (uint32_t j = s; j < e; ++j) {
-              const bool hit = op.near(c, tile[j]);
-              list[nl * THREADS + tid] = uint16_t(j);  // branch-free append: the slot is kept only on a hit
-              nl += hit ? 1u : 0u;
-              if (nl == lmax) flush();  // rare: a lane with more than lmax neighbours drains in order
-            }
-          }
-        flush();
-      } else {
-#pragma unroll 1
-        for (uint32_t dz = 0; dz < 3; ++dz)
-#pragma unroll 1
-          for (uint32_t dy = 0; dy < 3; ++dy) {
-            const uint32_t l0 = ((hz + dz) * 6u + (hy + dy)) * 6u + hx;
-            const uint32_t s = off[l0], e = off[l0 + 3];
-#pragma unroll 4
-            for (uint32_t j = s; j < e; ++j) op.add(c, tile[j]);
-          }
-      }
-      op.end(c, args, i);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Diffuse per CELL (option cell_diffuse, default on).  Diffuse has no distance test: a particle folds in
 // EVERY candidate of its 27 cells, in walk order, and only then looks at its own colour — so all the
@@ -1041,7 +914,7 @@ __global__ __launch_bounds__(THREADS) void k_gather_bricks(StepConsts<N> c, type
 // ------------------------------------------------------------------------------------------------
 // The same per-cell sums with the candidates staged through LDS: one workgroup owns a Morton-aligned
 // brick of 4 x 4 x 4 cells (64 consecutive codes), copies the colours of its 6 x 6 x 6 halo of cells
-// into LDS once (x-fastest, so the three x cells of a row are ONE LDS run, like k_gather_bricks) and one
+// into LDS once (x-fastest, so the three x cells of a row are ONE LDS run) and one
 // lane per home cell then folds its 9 runs in the reference's order.  One lane per cell straight from
 // global memory touches 64 different cache lines per load (measured: no faster than one lane per
 // particle); out of LDS the walk is bound by LDS bandwidth (64 cells x ~180 records x 16 B per brick;

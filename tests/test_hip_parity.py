@@ -74,12 +74,12 @@ def assert_state_equal(g, w, what=""):
 SCENES = ["cubes8192", "dam8192"]
 
 
-@pytest.fixture(params=["default", "global", "bricks", "tiles"])
+@pytest.fixture(params=["default", "global", "tiles"])
 def variant(request):
     """The gather kernels must all be bit-identical to the oracle: None = the product default (1 = neighbour
-    lists: quantised build + list-driven lambda / delta-p, per-cell diffuse), 0 = per-particle global walk,
-    2 = persistent LDS bricks."""
-    return {"default": None, "global": 0, "bricks": 2, "tiles": 3}[request.param]
+    lists: quantised build with lambda riding on it + list-driven delta-p, per-cell diffuse), 0 = per-particle global
+    walk, 3 = the iteration per brick out of LDS tiles (pbf_tiles.hpp)."""
+    return {"default": None, "global": 0, "tiles": 3}[request.param]
 
 # ------------------------------------------------------------------------------------------ A
 
@@ -127,8 +127,8 @@ def test_every_stage_bit_exact(pkg, oracle, scene, fp64, variant):
 @pytest.mark.parametrize("scene", SCENES)
 def test_free_running_bit_exact(pkg, oracle, scene, fp64, variant):
     """12 frames without re-seeding: GPU state == oracle(device_pow) state, bit for bit."""
-    if variant is not None and scene == "cubes8192" and (fp64 or variant != 3):
-        pytest.skip("alternative gather kernels run the dam-break scene (fp32 + fp64); the brick tiles also the cubes in fp32 (suite time)")
+    if variant is not None and (scene == "cubes8192" or (fp64 and variant == 0)):
+        pytest.skip("alternative gather kernels run the dam-break scene (the plain walk in fp32 only): suite time")
     sc, side = get_scene(pkg, scene, fp64)
     s, o = mk(pkg, oracle, sc, fp64, gather=variant)
     p, q = params_pair(pkg, oracle, side=side)
@@ -139,7 +139,7 @@ def test_free_running_bit_exact(pkg, oracle, scene, fp64, variant):
             assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
 
 
-@pytest.mark.parametrize("split,fp64", [(0, False), (4, False), (5, False), (8, False), (0, True), (5, True), (8, True)])
+@pytest.mark.parametrize("split,fp64", [(0, False), (4, False), (5, False), (8, False), (5, True), (8, True)])
 def test_split_build_bit_exact(pkg, oracle, split, fp64):
     """Option split_build: 0 = lambda builds the neighbour lists while it gathers; 4 / 5 = a list-build launch of
     its own (k_build_lists_q, 2 / 4 pair loads per trip) followed by a list-driven lambda; 8 (default) = the quantised
@@ -304,8 +304,9 @@ def test_obstacles_and_wells_bit_exact(pkg, oracle, variant):
 
 
 def test_tile_overflow_falls_back_bit_exact(pkg, oracle):
-    """A brick whose halo holds more records than the LDS tile takes the in-kernel global walk;
-    neighbours of that brick stay tiled.  5000 particles inside 3x3x3 cells force it."""
+    """gather = 3: a brick whose halo holds more records than the LDS tile takes the in-kernel global path (its rows
+    then hold global indices, every kernel of the iteration takes the same decision); neighbours of that brick stay
+    tiled.  5000 particles inside 3x3x3 cells force it."""
     rng = np.random.default_rng(11)
     pile = (rng.random((5000, 3)) * 140 + 430).astype(np.float32)
     far = (rng.random((3000, 3)) * 900 + 50).astype(np.float32)
@@ -313,7 +314,7 @@ def test_tile_overflow_falls_back_bit_exact(pkg, oracle):
     n = len(pos)
     sc = dict(id=np.arange(n, dtype=np.uint64), type=np.zeros(n, np.uint8), mass=np.ones(n, np.float32), pos=pos,
               vel=np.zeros((n, 3), np.float32), colour=rng.random((n, 4)).astype(np.float32))
-    s, o = mk(pkg, oracle, sc, False, gather=2)
+    s, o = mk(pkg, oracle, sc, False, gather=3)
     p, q = params_pair(pkg, oracle, iteration=2)
     s.step(p)
     o.step(q)
@@ -644,13 +645,13 @@ def test_steps_fuses_finalise_and_predict_bit_exact(pkg, oracle, fp64):
     sc = {k: v.copy() for k, v in sc.items()}
     sc["type"][::17] = 1
     p, q = params_pair(pkg, oracle, side=side, wells=[(0.5 * side, 0.4 * side, 0.5 * side, 900.0)])
-    a, o = mk(pkg, oracle, sc, fp64)          # fused: 3 calls of 4 steps
+    a, o = mk(pkg, oracle, sc, fp64)          # fused: 2 calls of 4 steps
     b = pkg.Solver(h=0.1, fp64=fp64)          # step by step
     b.upload(**sc)
     c = pkg.Solver(h=0.1, fp64=fp64)          # pbf_steps with the fusion off
     c.upload(**sc)
     c.set_option("fuse_predict", 0)
-    for chunk in range(3):
+    for chunk in range(2):
         a.steps(p, 4)
         c.steps(p, 4)
         for _ in range(4):
