@@ -47,6 +47,25 @@ def mk(pkg, oracle, scene, fp64, flags=0, device_pow=True, gather=None):
     return s, o
 
 
+_ORACLE_RUNS = {}
+
+
+def oracle_run(oracle, key, scene, fp64, q, frames, device_pow=True):
+    """The oracle's states after the given frames (0-based, last one = number of steps - 1) of a free run from `scene`,
+    computed once per key and shared by the tests that compare different GPU kernels against the same run (the CPU
+    oracle is what a parity test spends its time in)."""
+    if key not in _ORACLE_RUNS:
+        o = oracle.Oracle(fp64, device_pow=device_pow)
+        o.set_particles(**scene)
+        got = {}
+        for frame in range(max(frames) + 1):
+            o.step(q)
+            if frame in frames:
+                got[frame] = {k: np.array(v, copy=True) for k, v in o.get_particles().items()}
+        _ORACLE_RUNS[key] = got
+    return _ORACLE_RUNS[key]
+
+
 def params_pair(pkg, oracle, iteration=4, side=1000.0, wells=None):
     p = pkg.default_params(iteration, side)
     if wells is not None:
@@ -130,13 +149,13 @@ def test_free_running_bit_exact(pkg, oracle, scene, fp64, variant):
     if variant is not None and (scene == "cubes8192" or (fp64 and variant == 0)):
         pytest.skip("alternative gather kernels run the dam-break scene (the plain walk in fp32 only): suite time")
     sc, side = get_scene(pkg, scene, fp64)
-    s, o = mk(pkg, oracle, sc, fp64, gather=variant)
+    s, _ = mk(pkg, oracle, sc, fp64, gather=variant)
     p, q = params_pair(pkg, oracle, side=side)
+    want = oracle_run(oracle, ("free", scene, fp64), sc, fp64, q, (0, 2, 11))
     for frame in range(12):
         s.step(p)
-        o.step(q)
-        if frame in (0, 2, 11):
-            assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
+        if frame in want:
+            assert_state_equal(s.download(), want[frame], f"frame {frame}")
 
 
 @pytest.mark.parametrize("split,fp64", [(0, False), (4, False), (5, False), (8, False), (5, True), (8, True)])
@@ -148,14 +167,14 @@ def test_split_build_bit_exact(pkg, oracle, split, fp64):
     sc, side = get_scene(pkg, "dam8192", fp64)
     sc = {k: v.copy() for k, v in sc.items()}
     sc["type"][::13] = 1
-    s, o = mk(pkg, oracle, sc, fp64, gather=1)
+    s, _ = mk(pkg, oracle, sc, fp64, gather=1)
     s.set_option("split_build", split)
     p, q = params_pair(pkg, oracle, side=side)
+    want = oracle_run(oracle, ("split", fp64), sc, fp64, q, (0, 5))
     for frame in range(6):
         s.step(p)
-        o.step(q)
-        if frame in (0, 5):
-            assert_state_equal(s.download(), o.get_particles(), f"frame {frame}")
+        if frame in want:
+            assert_state_equal(s.download(), want[frame], f"frame {frame}")
 
 
 @pytest.mark.parametrize("cell", [0, 1])
