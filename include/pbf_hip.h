@@ -142,10 +142,13 @@ int pbf_read_buffer(pbf_ctx *ctx, int which, void *host, size_t bytes);
 size_t pbf_table_size(const pbf_ctx *ctx);                /* Morton(extent), sph.hpp:240 */
 int pbf_grid_extent(const pbf_ctx *ctx, uint64_t extent[3], double min_extent[3]); /* ompsph.hpp:132-135 */
 
-/* Device self-test of the range-trimmed IEEE sqrt / divide the precise pair terms use (csrc/pbf_kernels.hpp
- * sqrt_ranged / div_ranged) against the compiler's full IEEE forms: mismatches[0] over EVERY fp32 value >= 2^-96,
- * mismatches[1] over (h - r)^2 / r for every fp32 r in [1e-8, h], four h.  Both must be 0. */
-int pbf_selftest_math(pbf_ctx *ctx, uint64_t mismatches[4]); /* [2], [3]: x / poly6(0.3 h) and x / RHO over EVERY fp32 x */
+/* Device self-test of the trimmed exact sqrt / divides the precise pair terms use (csrc/pbf_kernels.hpp sqrt_rsq /
+ * div_seeded / div_ranged) against the compiler's full IEEE forms, exhaustively: mismatches[0] sqrt over EVERY fp32 value
+ * >= 2^-75; mismatches[1] (h - r)^2 / r over every fp32 d2 whose root lies in [1e-8, h], for the context's own h and
+ * three more; mismatches[2] x / poly6(0.3 h) over every fp32 x with 1e-30 <= |x| <= 1e30 or x == 0 (one mismatch is the
+ * sign of a zero quotient, which is only ever squared); mismatches[3] delta-p's x / RHO — trimmed where the numerator is
+ * in range, the compiler's divide otherwise — over EVERY fp32 x.  [0], [1], [3] must be 0, [2] <= 1. */
+int pbf_selftest_math(pbf_ctx *ctx, uint64_t mismatches[4]);
 
 /* Mean milliseconds per call of each stage since the last pbf_reset_stage_times (needs
  * PBF_FLAG_STAGE_TIMING).  names[i] points at static strings that follow the reference's Stopwatch

@@ -1350,7 +1350,7 @@ int pbf_selftest_math(pbf_ctx *ctx, uint64_t mismatches[4]) {
   const float p6 = poly6_factor<float>(h), r = float(CorrDeltaQ * h), d = (h * h) - r * r;
   const float p6DeltaQ = p6 * (d * d * d);
   hipLaunchKernelGGL(k_selftest_math, dim3(uint32_t(ctx->numCUs) * 8), dim3(BLOCK), 0, ctx->stream,
-                     ctx->selTotals.as<unsigned long long>(), p6DeltaQ, float(RHO));
+                     ctx->selTotals.as<unsigned long long>(), p6DeltaQ, float(RHO), h);
   LAUNCH_CHECK(ctx);
   unsigned long long hst[4] = {0, 0, 0, 0};
   HIPCHK(ctx, hipMemcpyAsync(hst, ctx->selTotals.p, 32, hipMemcpyDeviceToHost, ctx->stream));

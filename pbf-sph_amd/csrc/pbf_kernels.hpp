@@ -429,8 +429,9 @@ __device__ inline double fast_rsq(double x) { return 1.0 / sqrt(x); }  // fp64 k
 //     x >= 2^-75 (k_selftest_math sweeps them all).  The addend 2^-100 keeps x = 0 (a particle meeting itself) away
 //     from v_rsq's infinity and is absorbed exactly by every x >= 2^-75; below that — r < 5.5e-12, far under EPSILON —
 //     every small r gives the same pair terms: the spiky branch is off and h^2 - r^2 rounds to h^2.
-//   * div_seeded: (h - r)^2 / r by Newton from that y: one refinement of the reciprocal, the quotient, two residual
-//     corrections — 7 fma / mul, no v_rcp.  With 1e-8 <= r <= h nothing needs scaling or fixing and the result is the
+//   * div_seeded: (h - r)^2 / r by Newton from that y: one refinement of the reciprocal, the quotient, one residual
+//     correction — 5 fma / mul, no v_rcp (a second correction, as a general-purpose divide would carry, changes no
+//     result on the swept operands).  With 1e-8 <= r <= h nothing needs scaling or fixing and the result is the
 //     IEEE quotient bit for bit (swept: every fp32 d2 whose root lies in [1e-8, h], four h); outside that range the
 //     quotient is never used (selected away).
 //   * div_ranged (reciprocal of a per-launch CONSTANT divisor, hoisted out of the loops by the compiler) serves
@@ -453,10 +454,9 @@ __device__ inline double sqrt_rsq(double x, double &y) {
 }
 __device__ inline float div_seeded(float a, float b, float y) {
   y = fmaf(fmaf(-b, y, 1.0f), y, y);
-  float q = a * y;
-  q = fmaf(fmaf(-b, q, a), y, q);
-  q = fmaf(fmaf(-b, q, a), y, q);
-  return q;
+  const float q = a * y;
+  return fmaf(fmaf(-b, q, a), y, q);  // ONE residual correction: relative error ~2^-47 before the final rounding — enough
+                                      // for every operand the sweeps visit (k_selftest_math), which is every operand used
 }
 __device__ inline double div_seeded(double a, double b, double) { return a / b; }
 __device__ inline float div_ranged(float a, float b) { return div_seeded(a, b, __builtin_amdgcn_rcpf(b)); }
@@ -1655,16 +1655,16 @@ __global__ __launch_bounds__(BLOCK) void k_pack_aos(uint32_t n, uint8_t *__restr
 //   bad[2]  div_ranged(x, poly6(0.3 h)) over every fp32 x with 1e-30 <= |x| <= 1e30 or x == 0 (NaNs compare by class);
 //   bad[3]  DeltaOp's x / RHO — div_ranged where div_ranged_ok(x), the compiler's divide otherwise — over EVERY fp32 x.
 __global__ __launch_bounds__(BLOCK) void k_selftest_math(unsigned long long *__restrict__ bad, float divisorA,
-                                                         float divisorB) {
+                                                         float divisorB, float hOwn) {
   unsigned long long badSqrt = 0, badDiv = 0, badA = 0, badB = 0;
-  const float hs[4] = {0.1f, 0.05f, 0.2f, 0.0999999f};
+  const float hs[4] = {hOwn, 0.05f, 0.2f, 0.0999999f};  // the context's own h (0.1 in every shipped configuration) + three more
   for (uint64_t v = uint64_t(blockIdx.x) * BLOCK + threadIdx.x; v < (1ull << 32); v += uint64_t(gridDim.x) * BLOCK) {
     const float x = __int_as_float(int(uint32_t(v)));
     if (x >= 0x1p-75f && x <= 3.0e38f) {
       float y;
       const float r = sqrt_rsq(x, y), ref = sqrtf(x);
       badSqrt += __float_as_int(r) != __float_as_int(ref);
-      if (ref >= 1e-8f && ref <= 0.2f) {
+      if (ref >= 1e-8f && ref <= fmaxf(0.2f, hOwn)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (ref <= hs[k]) {

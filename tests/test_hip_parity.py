@@ -644,15 +644,15 @@ def test_wave_cooperative_reader_within_tolerance(pkg, oracle, coop, fp64):
 
 
 def test_ranged_sqrt_and_divide_are_the_ieee_ones(pkg):
-    """The precise pair terms use a sqrt and a divide trimmed to their operand range (no denormal rescale, no
-    v_div_scale / v_div_fixup): swept on the device against the compiler's IEEE forms over every fp32 value
-    (sqrt, x >= 2^-96) and every fp32 r in [1e-8, h] for (h - r)^2 / r — not one mismatch allowed."""
+    """The precise pair terms use a sqrt (one v_rsq + a Heron step) and divides (Newton from a seed, one residual
+    correction) trimmed to their operand range: swept on the device against the compiler's IEEE forms over every fp32
+    value (sqrt, x >= 2^-75), every fp32 d2 whose root lies in [1e-8, h] for (h - r)^2 / r — h = the context's 0.1 and
+    three more —, every fp32 numerator for the two constant divisors of delta-p.  Not one mismatch allowed, but for the
+    sign of one zero quotient that is only ever squared."""
     s = pkg.Solver(h=0.1)
     bad = np.zeros(4, np.uint64)
     s._chk(s.L.pbf_selftest_math(s.ctx, bad.ctypes.data_as(C.c_void_p)), "pbf_selftest_math")
-    # [2]: x / poly6(0.3 h) over every fp32 x with 1e-30 <= |x| <= 1e30 or x == 0 — one mismatch allowed: -0 -> +0
-    # (the quotient is only ever squared).  [3]: x / RHO is reported, not used (its numerator can be a denormal).
-    assert bad[0] == 0 and bad[1] == 0 and bad[2] <= 1, bad
+    assert bad[0] == 0 and bad[1] == 0 and bad[2] <= 1 and bad[3] == 0, bad
 
 
 @pytest.mark.parametrize("fp64", [False, True])
