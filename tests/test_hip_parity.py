@@ -682,6 +682,19 @@ def test_steps_fuses_finalise_and_predict_bit_exact(pkg, oracle, fp64):
         assert_state_equal(ga, o.get_particles(), f"chunk {chunk}")
 
 
+@pytest.mark.parametrize("iteration", [0, 1])
+def test_steps_fusion_with_few_iterations(pkg, oracle, iteration):
+    """pbf_steps' fused finalise(t) + predict(t + 1) with K = 0 (predict, sort, finalise only) and K = 1: equal to the
+    oracle."""
+    sc, side = get_scene(pkg, "dam8192", False)
+    s, o = mk(pkg, oracle, sc, False)
+    p, q = params_pair(pkg, oracle, iteration=iteration, side=side)
+    s.steps(p, 3)
+    for _ in range(3):
+        o.step(q)
+    assert_state_equal(s.download(), o.get_particles())
+
+
 @pytest.mark.parametrize("fp64", [False, True])
 def test_graph_replay_bit_exact(pkg, oracle, fp64):
     """pbf_steps can replay each distinct step as a captured hipGraph (option graph; off by default: measured slower than
