@@ -78,12 +78,14 @@ void pbf_destroy(pbf_ctx *ctx);
 /* ctx may be NULL: last error of a failed pbf_create on this thread */
 const char *pbf_last_error(const pbf_ctx *ctx);
 int pbf_abi_version(void);
-/* Tuning / diagnostic knobs (no reference counterpart): "gather" (0 global walk, 1 neighbour lists, 3 LDS tiles per brick),
- * "list_max", "tile_cap", "reuse_lists", "split_build" (0 lambda builds the lists itself, 4 / 5 list-build launch with 2 / 4 pair loads per trip,
- * default 5), "coop" (0 = one lane per particle in the list-driven lambda / delta-p, bit-exact, default; 2 / 4 / 8 = that many
- * lanes share a particle's list and reduce the kernel sums with wave shuffles: rounding-level differences),
- * "cell_diffuse" (one colour walk per occupied cell, default 1), "fuse_diffuse", "timing_mask" (bit i = stage i of pbf_stage_times is bracketed with events).
- * Unknown names return PBF_ERR_INVALID. */
+/* Tuning / diagnostic knobs (no reference counterpart): "gather" (0 global walk, 1 neighbour lists = default, 3 LDS tiles
+ * per brick), "list_max", "tile_cap", "reuse_lists", "split_build" (0 = lambda builds the lists while it gathers; 4 / 5 = a
+ * list-build launch of its own with 2 / 4 pair loads per trip, then a list-driven lambda; 8 = DEFAULT: the quantised list
+ * build with lambda riding on its flushes, one launch), "coop" (0 = one lane per particle in the list-driven lambda /
+ * delta-p, bit-exact, default; 2 / 4 / 8 = that many lanes share a particle's list and reduce the kernel sums with wave
+ * shuffles: rounding-level differences), "cell_diffuse" (one colour walk per occupied cell, default 1), "fuse_diffuse",
+ * "overlap_diffuse", "fuse_predict", "pipeline", "graph", "pad_lds", "timing_mask" (bit i = stage i of pbf_stage_times is
+ * bracketed with events).  Unknown names return PBF_ERR_INVALID. */
 int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value);
 
 /* ---- particle state (replaces the std::vector<Particle>& in/out argument, src/sph.hpp:124) */
@@ -136,7 +138,9 @@ enum pbf_buffer {
   PBF_BUF_PSTAR = 2,  /* N[4n]: pStar.xyz, lambda */
   PBF_BUF_NBR_COUNT = 3, /* uint32[n]: neighbour-list length per particle of the last list build (0xFFFFFFFF =
                             the row overflowed and the particle walks its cells); diagnostic, list gather only */
-  PBF_BUF_COUNT_ = 4,
+  PBF_BUF_OMEGA = 4,  /* N[4n]: {omega.xyz, 0}, the vorticity estimate of the last step run with pbf_params.vorticity
+                         (opt-in extra, absent from the reference), device order; PBF_ERR_STATE when there is none */
+  PBF_BUF_COUNT_ = 5,
 };
 int pbf_read_buffer(pbf_ctx *ctx, int which, void *host, size_t bytes);
 size_t pbf_table_size(const pbf_ctx *ctx);                /* Morton(extent), sph.hpp:240 */

@@ -413,7 +413,9 @@ template <typename N> struct Oracle final : pbf_oracle {
         const N r = distance(pStar[a], pStar[b]);
         const V3<N> g = spikyKernelGradient(pStar[a], pStar[b], r, h, SpikyKernelFactor);
         const V3<N> vij = v[b] - v[a];
-        w = w + V3<N>{vij.y * g.z - vij.z * g.y, vij.z * g.x - vij.x * g.z, vij.x * g.y - vij.y * g.x};
+        // Macklin & Mueller 2013 eq. 15: omega_i = sum_j v_ij x grad_{p_j} W(p_i - p_j), v_ij = v_j - v_i.  The gradient is
+        // with respect to the NEIGHBOUR: grad_{p_j} W = -grad_{p_i} W = -g, hence v_ij x (-g) = g x v_ij.
+        w = w + V3<N>{g.y * vij.z - g.z * vij.y, g.z * vij.x - g.x * vij.z, g.x * vij.y - g.y * vij.x};
       });
       omega[a] = w;
     });

@@ -16,6 +16,7 @@ FLAG_NO_LDS = 1 << 2
 
 BUF_KEYS, BUF_TABLE, BUF_PSTAR = 0, 1, 2
 BUF_NBR_COUNT = 3
+BUF_OMEGA = 4
 
 
 class PbfError(RuntimeError):
@@ -324,6 +325,12 @@ class Solver:
         a = np.empty((self.n, 4), self.dtype)
         self._chk(self.L.pbf_read_buffer(self.ctx, BUF_PSTAR, _vp(a), a.nbytes), "read pstar")
         return a
+
+    def omega(self):
+        """(n,3): vorticity estimate of the last step run with p.vorticity (opt-in extra), device order"""
+        a = np.empty((self.n, 4), self.dtype)
+        self._chk(self.L.pbf_read_buffer(self.ctx, BUF_OMEGA, _vp(a), a.nbytes), "read omega")
+        return a[:, :3].copy()
 
     def surface(self, p, mc=None):
         """Marching cubes on the state the last step left -> dict(vs, ns, cs, sample, pn, c)."""

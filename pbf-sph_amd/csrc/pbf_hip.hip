@@ -119,6 +119,7 @@ struct pbf_ctx {
   DevBuf qpos;               // 8-byte quantised pStar for the list build (k_build_lists_q)
   DevBuf nbrList, nbrCount;  // neighbour lists handed from the lambda launch to the delta launch (NBR_CAP per particle)
   bool nbrValid = false;     // the lists describe pstar[pcur] as it is now
+  bool omegaValid = false;   // pstar[2] holds the vorticity of the last extras pass (PBF_BUF_OMEGA), same order as the arrays
   // advance() path: the caller's std::vector<Particle> buffer, page-locked in place (hipHostRegister) so the per-frame
   // 56-byte-per-particle upload and download are plain DMA instead of the runtime's pageable staging
   void *regPtr = nullptr;
@@ -421,6 +422,7 @@ template <typename N> int stage_predict(pbf_ctx *ctx, const pbf_params *p) {
   ctx->sorted = false;
   ctx->nbrValid = false;
   ctx->qposValid = false;
+  ctx->omegaValid = false;
   ctx->counted = true;
   ctx->countedTableN = c.tableN;
   return PBF_OK;
@@ -619,6 +621,7 @@ template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p, bool 
                                    ctx->type[s].as<const uint8_t>()};
   const bool timed = (ctx->desc.flags & PBF_FLAG_STAGE_TIMING) != 0 && ((ctx->timingMask >> ST_DIFFUSE) & 1u) != 0;
   overlap = overlap && ctx->overlapDiffuse && ctx->cellDiffuse && !(ctx->desc.flags & PBF_FLAG_NO_LDS) && !timed;
+  ctx->omegaValid = false;  // (the per-cell sums may be parked in pStar's idle Jacobi partner)
   StageTimer t(ctx, ST_DIFFUSE);
   if (ctx->cellDiffuse && !(ctx->desc.flags & PBF_FLAG_NO_LDS)) {
     // sums per cell, parked in buffers that are idle here (the Jacobi partner of pStar and the list lengths) — or, when
@@ -716,6 +719,7 @@ template <typename N> int stage_delta(pbf_ctx *ctx, const pbf_params *p) {
   const int s = ctx->cur, in = ctx->pcur, out = other_pstar(ctx);
   const GatherMode from = ctx->nbrValid ? GATHER_FROM_LISTS : GATHER_PLAIN;
   ctx->nbrValid = false;  // delta moves pStar: the lists are stale afterwards
+  ctx->omegaValid = false;  // (and may write the buffer the last vorticity pass left its result in)
   int rc;
   // delta-p's epilogue also writes the quantised copy of the new pStar: the next iteration's list build needs it
   uint2 *qp = ctx->qposValid ? ctx->qpos.as<uint2>() : nullptr;
@@ -745,6 +749,7 @@ template <typename N, bool FAST> int extras_impl(pbf_ctx *ctx, const pbf_params 
     typename VorticityForceOp<N, FAST>::Args a2{ps, omega, ctx->vel4[s].as<const vec4<N>>(), ctx->vel4[o].as<vec4<N>>(), type};
     if (int rc = launch_gather<N, VorticityForceOp<N, FAST>>(ctx, c, a2)) return rc;
     std::swap(ctx->vel4[s], ctx->vel4[o]);
+    ctx->omegaValid = true;
   }
   if (p->xsph) {
     typename XsphOp<N, FAST>::Args a3{ps, ctx->vel4[s].as<const vec4<N>>(), ctx->vel4[o].as<vec4<N>>(), type};
@@ -779,7 +784,7 @@ template <typename N> int stage_finalise(pbf_ctx *ctx, const pbf_params *p) {
                        ctx->vel4[s].as<vec4<N>>(), ctx->wells.as<const N>(), ctx->key[s].as<uint32_t>(),
                        ctx->count.as<uint32_t>());
     LAUNCH_CHECK(ctx);
-    ctx->sorted = false, ctx->nbrValid = false, ctx->qposValid = false;
+    ctx->sorted = false, ctx->nbrValid = false, ctx->qposValid = false, ctx->omegaValid = false;
     ctx->counted = true, ctx->countedTableN = c.tableN;
     ctx->prePredicted = true;
     return PBF_OK;
@@ -1331,6 +1336,10 @@ int pbf_read_buffer(pbf_ctx *ctx, int which, void *host, size_t bytes) {
       break;
     case PBF_BUF_PSTAR: src = ctx->pstar[ctx->pcur].p, avail = ctx->n * v; break;
     case PBF_BUF_NBR_COUNT: src = ctx->nbrCount.p, avail = (ctx->ghostsPending ? ctx->nOwned : ctx->n) * 4; break;
+    case PBF_BUF_OMEGA:
+      if (!ctx->omegaValid) return fail(ctx, PBF_ERR_STATE, "no vorticity pass since the arrays last changed (pbf_params.vorticity)");
+      src = ctx->pstar[2].p, avail = ctx->n * v;
+      break;
     default: return fail(ctx, PBF_ERR_INVALID, "unknown buffer");
   }
   if (bytes > avail) return fail(ctx, PBF_ERR_INVALID, "read beyond buffer");

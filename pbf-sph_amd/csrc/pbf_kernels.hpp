@@ -713,7 +713,11 @@ template <typename N> struct PosVel {
   vec4<N> p, v;
 };
 
-// omega_a = sum_b (v_b - v_a) x grad spiky(a, b)
+// omega_a = sum_b (v_b - v_a) x grad_{p_b} W(p_a - p_b)        (Macklin & Mueller 2013 eq. 15: the gradient is taken
+// with respect to the NEIGHBOUR's position, = -grad_{p_a} W = -spikyKernelGradient(a, b)), accumulated as
+// grad_{p_a} W x (v_b - v_a) — the same number, each component the exact negation of (v_b - v_a) x grad_{p_a} W.
+// A rigid rotation about +z then gives omega along +z (curl v = 2 Omega), tests/test_physics_gpu.py.
+// (Rounds 1-2 accumulated (v_b - v_a) x grad_{p_a} W: the sign was flipped, the confinement force decelerated vortices.)
 template <typename N, bool FAST> struct VorticityOp {
   using Src = PosVel<N>;
   struct Args {
@@ -744,7 +748,7 @@ template <typename N, bool FAST> struct VorticityOp {
     const N s = c.spikyFactor * g.hr2_over_r;
     const N gx = g.inSpiky ? g.dx * s : N(0), gy = g.inSpiky ? g.dy * s : N(0), gz = g.inSpiky ? g.dz * s : N(0);
     const N ux = b.v.x - va.x, uy = b.v.y - va.y, uz = b.v.z - va.z;
-    wx = wx + (uy * gz - uz * gy), wy = wy + (uz * gx - ux * gz), wz = wz + (ux * gy - uy * gx);
+    wx = wx + (gy * uz - gz * uy), wy = wy + (gz * ux - gx * uz), wz = wz + (gx * uy - gy * ux);
   }
   __device__ void end(const StepConsts<N> &, const Args &a, uint32_t i) { a.omega[i] = make_vec4<N>(wx, wy, wz, N(0)); }
 };

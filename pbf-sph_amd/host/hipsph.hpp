@@ -106,7 +106,17 @@ inline std::vector<uint32_t> recut(const std::vector<uint32_t> &old, const std::
 
 }  // namespace detail
 
+// V: the vector template of the hosting code base — the reference instantiates its API with glm::vec (src/omp/ompsph.hpp:33),
+// this repo's host/sph.hpp ships sph::vec and announces it with PBF_SPH_HAS_VEC, which only supplies a default here.  Built
+// against the REFERENCE's own src/sph.hpp (no sph::vec there) the argument is mandatory: oracle/ref_shim.cpp does exactly
+// that, so the "copy two headers, add a case" recipe of INTEGRATION.md is compiled, linked and run by the test-suite.
+// What V must offer (glm::vec does): x / y / z[/ w] members, V<3>(a, b, c) from mixed arithmetic types, V<3> + V<3>,
+// V<3> - V<3>, V<3> * N, and a packed layout.
+#ifdef PBF_SPH_HAS_VEC
 template <typename T, typename N, template <size_t, typename C = N> typename V = sph::vec>
+#else
+template <typename T, typename N, template <size_t, typename C = N> typename V>
+#endif
 class Solver final : public sph::Solver<T, N, V> {
   static_assert(std::is_same_v<N, float> || std::is_same_v<N, double>, "N must be float or double");
   static_assert(sizeof(T) == 8, "ids travel as 64-bit (the reference instantiates T = size_t)");

@@ -27,6 +27,7 @@
 namespace sph {
 
 // ---- a minimal vector type usable as the V template argument ---------------------------------
+#define PBF_SPH_HAS_VEC 1  // (hipsph.hpp: sph::vec exists and is the default V; the reference's sph.hpp has no such type)
 template <size_t L, typename T> struct vec;
 template <typename T> struct vec<3, T> {
   T x{}, y{}, z{};

@@ -209,10 +209,15 @@ def test_pipelined_readers_bit_exact(pkg, oracle, pipeline, fp64):
     s, o = mk(pkg, oracle, sc, fp64)
     s.set_option("pipeline", pipeline)
     p, q = params_pair(pkg, oracle, side=side)
+    # the pile really overflows its rows (so the readers' walking fallback is what is being compared): the first list
+    # build of the run marks more than 64 survivors as NBR_OVERFLOW
+    probe = pkg.Solver(h=0.1, fp64=fp64)
+    probe.set_option("pipeline", pipeline)
+    probe.upload(**sc).stage("predict", p).stage("sort", p).stage("lambda", p)
+    assert (probe.nbr_counts() == 0xFFFFFFFF).sum() >= 100
     for frame in range(4):
         s.step(p)
         o.step(q)
-    assert (s.nbr_counts() == 0xFFFFFFFF).sum() > 0 or frame > 0
     assert_state_equal(s.download(), o.get_particles())
 
 
@@ -638,7 +643,7 @@ def test_wave_cooperative_reader_within_tolerance(pkg, oracle, coop, fp64):
     assert np.array_equal(g["id"], w["id"])                      # same sort, same permutation
     d = np.linalg.norm(g["pos"].astype(np.float64) - w["pos"], axis=1)
     assert d.max() <= (1e-3 if not fp64 else 1e-9), d.max()
-    assert not np.array_equal(g["pos"], w["pos"]) or fp64 or coop == 0  # (it really is another summation order)
+    assert not np.array_equal(g["pos"], w["pos"])  # it really is another summation order, in either precision
     dv = np.abs(g["vel"].astype(np.float64) - w["vel"]).max()
     assert dv <= (1e-3 if not fp64 else 1e-9), dv
 
