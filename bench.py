@@ -51,7 +51,25 @@ KERNEL_OF = {"sph-lambda/list-build": "k_build_lists_q", "sph-lambda": "k_build_
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 SPLIT_STEPS = 10
 PROBE_STEPS = 10
-TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+# committed counter summaries of THIS command line (tools/r03_profiles.sh); the newest round present is quoted, by name
+TRAFFIC_FILES = [os.path.join("profiles", f"r0{r}_pmc_traffic.json") for r in (3, 2)]
+LIMITER_FILES = [os.path.join("profiles", f"r0{r}_limiter.json") for r in (3,)]
+
+
+def first_existing(paths):
+    for f in paths:
+        if os.path.exists(os.path.join(ROOT, f)):
+            return f
+    return None
+
+
+def match_kernel(table, kname):
+    """entry of a {rocprofv3 kernel name: ...} table for a KERNEL_OF name like 'k_gather_from_lists<DeltaOp>'"""
+    base, toks = kname.split("<")[0], kname.replace(">", "").split("<")[1:]
+    for name, v in table.items():
+        if base in name and all(t in name for t in toks):
+            return v
+    return None
 
 
 def candidates_per_particle(keys, table):
@@ -112,6 +130,28 @@ def _time_oracle(O, so_path, state, side, fp64, iteration, threads, budget_s, ma
     return steps, t
 
 
+def host_cores():
+    """(physical cores, hardware threads) this process may run on: distinct (physical id, core id) pairs of
+    /proc/cpuinfo among the CPUs of the affinity mask.  north_star asks for the CORE count; OpenMP runs one thread per
+    hardware thread, reported beside it."""
+    cpus = os.sched_getaffinity(0)
+    cores, cur = set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = (t.strip() for t in line.split(":", 1))
+                cur[k] = v
+            elif cur:
+                if int(cur.get("processor", -1)) in cpus:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+        if cur and int(cur.get("processor", -1)) in cpus:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except OSError:
+        pass
+    return (len(cores) or len(cpus)), len(cpus)
+
+
 def cpu_baseline(state, side, fp64, iteration, budget_s=9.0, max_steps=6):
     """Time the oracle (the checker's source, kind 'port') on the host cores: a bounded sample of the SAME workload,
     started from the GPU's post-run state.  BASELINE.md §4: -O3 -march=native without fast-math is `value`; the
@@ -120,7 +160,7 @@ def cpu_baseline(state, side, fp64, iteration, budget_s=9.0, max_steps=6):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
-    threads = len(os.sched_getaffinity(0))
+    cores, threads = host_cores()
     n = len(state["id"])
     try:
         native = O.build_native()
@@ -132,9 +172,10 @@ def cpu_baseline(state, side, fp64, iteration, budget_s=9.0, max_steps=6):
         steps, t = _time_oracle(O, path, state, side, fp64, iteration, threads, budget_s, max_steps)
         res.append({"flags": flags, "value": n * steps / t, "ms_per_step": 1e3 * t / steps, "steps": steps, "seconds": t})
     main = res[0]
-    out = {"value": main["value"], "unit": "particle-steps/s", "cores": threads, "kind": "port",
+    out = {"value": main["value"], "unit": "particle-steps/s", "cores": cores, "threads": threads, "kind": "port",
            "sample": f"{main['steps']} steps of the same {n}-particle dam-break state after the timed region "
-                     f"(oracle Jacobi mode, OpenMP, {main['flags']}), {main['seconds']:.1f} s",
+                     f"(oracle Jacobi mode, OpenMP on {threads} hardware threads = {cores} physical cores, "
+                     f"{main['flags']}), {main['seconds']:.1f} s",
            "ms_per_step": main["ms_per_step"], "flags": main["flags"]}
     if len(res) > 1:
         out["reference_release_flags"] = {"flags": res[1]["flags"], "value": res[1]["value"],
@@ -191,8 +232,9 @@ def main():
                          "default 1 M (N = 1, weak) / 4 M (strong, BASELINE.json configs[3])")
     ap.add_argument("--solver-iter", type=int, default=4)
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
-                    help="N > 1: strong (default) = ONE dam-break column cut into N load-balanced x-slabs; "
-                         "weak = N mirrored 1 M columns side by side")
+                    help="strong (default for N > 1) = ONE 4 M dam-break column cut into N load-balanced x-slabs — with "
+                         "--gpus 1 the whole 4 M column on one GPU, the first point of a like-for-like sweep; weak "
+                         "(default for N = 1) = 1 M per GPU, N mirrored columns side by side")
     ap.add_argument("--settle-to", type=int, default=200,
                     help="simulation frame at which the timed region starts when warmup is smaller (reference CLI "
                          "warm-up default, args.hpp:36)")
@@ -245,7 +287,9 @@ def main():
     flags = (0 if os.environ.get("PBF_BENCH_NO_EVENTS") else pkg.FLAG_STAGE_TIMING) | \
         (pkg.FLAG_FAST_MATH if args.fast_math else 0) | (pkg.FLAG_NO_LDS if args.no_lds else 0)
     scaling = args.scaling or ("strong" if world > 1 else "weak")
-    nominal = args.particles or ((1 << 22) if (scaling == "strong" and world > 1) else (1 << 20))
+    # --scaling strong = BASELINE.json configs[3]'s ONE 4 M column whatever N is (N = 1: the whole column on one GPU, the
+    # like-for-like first point of a strong-scaling sweep); default: N = 1 -> the 1 M headline config, N > 1 -> strong
+    nominal = args.particles or ((1 << 22) if scaling == "strong" else (1 << 20))
     scene, side = pkg.scene_dambreak(nominal, args.fp64)
     n = len(scene["id"])
     p = pkg.default_params(args.solver_iter, side)
@@ -382,14 +426,24 @@ def main():
         # HBM bytes per launch of the dominant kernel: NOT measured in this run (PMC counters need rocprofv3) — read
         # from the committed separate --pmc passes of this same command line (FETCH_SIZE and WRITE_SIZE collected
         # separately, 2 x FETCH gfx950 correction) and only for the configuration those passes ran
-        traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, TRAFFIC_FILE)
-        if world == 1 and not args.fp64 and nominal == (1 << 20) and not args.fast_math and os.path.exists(tfile):
-            kname = KERNEL_OF.get(dom, dom)
-            for name, t in json.load(open(tfile)).items():
-                if kname.split("<")[0] in name and all(tok in name for tok in kname.replace(">", "").split("<")[1:]):
-                    traffic = t["hbm_bytes_gfx950_corrected"]
-                    traffic_src = f"file: {TRAFFIC_FILE} (rocprofv3 --pmc passes of this command, not this run)"
+        traffic, traffic_src, limiter = None, None, None
+        headline = world == 1 and not args.fp64 and nominal == (1 << 20) and not args.fast_math
+        tfile, lfile = first_existing(TRAFFIC_FILES), first_existing(LIMITER_FILES)
+        if headline and tfile:
+            t = match_kernel(json.load(open(os.path.join(ROOT, tfile))), KERNEL_OF.get(dom, dom))
+            if t:
+                traffic = t["hbm_bytes_gfx950_corrected"]
+                traffic_src = f"file: {tfile} (rocprofv3 --pmc passes of this command, not this run)"
+        if headline and lfile:
+            # what binds the kernel, as MEASURED by the SQ / TA counter passes of this command (not this run): nothing here
+            # is an HBM-bound kernel, the HBM fractions above are reported because the contract asks for them
+            lim = match_kernel(json.load(open(os.path.join(ROOT, lfile))), KERNEL_OF.get(dom, dom))
+            if lim:
+                limiter = dict(lim, source=f"file: {lfile} (rocprofv3 --pmc SQ / TA passes of this command, not this run)")
+        # SURVEY.md §8(d)-STRICT fraction: only the stage's algorithmic bytes (lambda: 12 R + 4 W; the neighbour list is an
+        # implementation artefact §8(d) does not count); the own-accounting figure above also prices the list the kernel writes
+        strict_bytes = sb.get(dom.split("/")[0], dom_bytes)
+        achieved_strict = strict_bytes * n_rank / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         out = {
             "metric": "particle-steps/sec (1 M particles, 4 iters) + achieved HBM GB/s, 1/2/4/8 MI355X",
             "value": value,
@@ -422,11 +476,17 @@ def main():
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stopwatch_entry": dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "achieved_strict": achieved_strict, "frac_strict": achieved_strict / HBM_PEAK_GBS,
+                         "strict_bytes_per_particle": strict_bytes,
+                         "strict_note": "SURVEY.md §8(d) bytes of the stage only (the neighbour list the kernel writes is not counted)",
+                         "limiter": limiter,
                          "algorithmic_bytes_per_particle": dom_bytes, "algorithmic_bytes_note": dom_bytes_note,
                          "mean_launch_ms": dom_ms, "launches_timed": dom_calls,
                          "whole_step_GBs": value * bytes_step / 1e9 / world,
                          "whole_step_frac": value * bytes_step / 1e9 / world / HBM_PEAK_GBS,
-                         "note": "the neighbour kernels are instruction-issue / latency bound, not HBM-bound (SURVEY.md §8d)"},
+                         "note": "`bound` names the roofline `peak` is taken from (the contract's HBM figure); the kernel itself "
+                                 "is NOT HBM-bound — `limiter` holds the measured issue / texture-path / occupancy figures "
+                                 "(SURVEY.md §8d: the neighbour kernels are instruction-issue / latency bound)"},
             "lists": {"mean_list_length": mean_list, "overflow_fraction": overflow},
             # the step's pure streams for contrast ("where >= 50 % of 8 TB/s is physically meaningful")
             "roofline_streaming": {k: {"achieved": sb[k] * n_rank / (split[k][0] * 1e-3) / 1e9, "unit": "GB/s",
@@ -465,7 +525,7 @@ def main():
                 oo = O.Oracle(args.fp64, device_pow=not args.fast_math)
                 oo.set_particles(**state)
                 oo.step(O.make_params(iteration=args.solver_iter, max_bound=(side,) * 3, mode=O.JACOBI,
-                                      sort=O.SORT_STABLE, threads=cb["cores"]))
+                                      sort=O.SORT_STABLE, threads=cb["threads"]))
                 o2_state = oo.get_particles()
             except Exception as e:  # the check is informative here; tests/ are the gate
                 out["parity_check_error"] = str(e)

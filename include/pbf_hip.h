@@ -136,8 +136,10 @@ enum pbf_buffer {
   PBF_BUF_KEYS = 0,   /* uint32[n]  Morton cell key per particle, current device order */
   PBF_BUF_TABLE = 1,  /* uint32[table_size] = the reference's gridTable (sph.hpp:238-250) */
   PBF_BUF_PSTAR = 2,  /* N[4n]: pStar.xyz, lambda */
-  PBF_BUF_NBR_COUNT = 3, /* uint32[n]: neighbour-list length per particle of the last list build (0xFFFFFFFF =
-                            the row overflowed and the particle walks its cells); diagnostic, list gather only */
+  PBF_BUF_NBR_COUNT = 3, /* uint32[n]: neighbour list of each particle after the last list build: low 8 bits = length (<= 64),
+                            upper 24 bits = the pool chunk holding its slots 40..63 when the length exceeds 40 (two-tier
+                            lists, csrc/pbf_kernels.hpp NbrLists); 0xFFFFFFFF = more than 64 survivors (or the chunk pool ran
+                            dry): the particle walks its cells; diagnostic, list gather only */
   PBF_BUF_OMEGA = 4,  /* N[4n]: {omega.xyz, 0}, the vorticity estimate of the last step run with pbf_params.vorticity
                          (opt-in extra, absent from the reference), device order; PBF_ERR_STATE when there is none */
   PBF_BUF_COUNT_ = 5,
@@ -151,7 +153,11 @@ int pbf_grid_extent(const pbf_ctx *ctx, uint64_t extent[3], double min_extent[3]
  * >= 2^-75; mismatches[1] (h - r)^2 / r over every fp32 d2 whose root lies in [1e-8, h], for the context's own h and
  * three more; mismatches[2] x / poly6(0.3 h) over every fp32 x with 1e-30 <= |x| <= 1e30 or x == 0 (one mismatch is the
  * sign of a zero quotient, which is only ever squared); mismatches[3] delta-p's x / RHO — trimmed where the numerator is
- * in range, the compiler's divide otherwise — over EVERY fp32 x.  [0], [1], [3] must be 0, [2] <= 1. */
+ * in range, the compiler's divide otherwise — over EVERY fp32 x.  [0], [1], [3] must be 0, [2] <= 1.
+ * On an fp64 context the same four categories are swept for the fp64 forms (v_rsq_f64-seeded sqrt = the compiler's own
+ * sequence without its rescale wrappers; Newton divides with one exact-residual correction) over 1.07e10 pseudo-random
+ * operands EACH (an exhaustive fp64 sweep is impossible): every exponent of the stated ranges equally often plus the pair
+ * terms' own operand ranges densely (csrc/pbf_kernels.hpp k_selftest_math64); all four must be 0. */
 int pbf_selftest_math(pbf_ctx *ctx, uint64_t mismatches[4]);
 
 /* Mean milliseconds per call of each stage since the last pbf_reset_stage_times (needs

@@ -308,7 +308,8 @@ class Solver:
         """Neighbour-list length per particle of the last list build (0xFFFFFFFF: overflowed row)."""
         k = np.empty(self.n, np.uint32)
         self._chk(self.L.pbf_read_buffer(self.ctx, BUF_NBR_COUNT, _vp(k), k.nbytes), "read neighbour counts")
-        return k
+        # raw word = length | chunk << 8 (the chunk of the list's slots beyond the 40 in the rows), or 0xFFFFFFFF
+        return np.where(k == 0xFFFFFFFF, k, k & 0xFF).astype(np.uint32)
 
     def keys(self):
         k = np.empty(self.n, np.uint32)

@@ -117,7 +117,9 @@ struct pbf_ctx {
   uint64_t mcSample[3] = {0, 0, 0};
   uint64_t mcTriangles = 0;
   DevBuf qpos;               // 8-byte quantised pStar for the list build (k_build_lists_q)
-  DevBuf nbrList, nbrCount;  // neighbour lists handed from the lambda launch to the delta launch (NBR_CAP per particle)
+  DevBuf nbrList, nbrCount;  // neighbour lists handed from the lambda launch to the delta launch: NBR_ROWS slots per particle
+  DevBuf nbrExtra;           // ... + chunks of NBR_EXTRA more slots for the particles that need them (NbrLists)
+  uint32_t nbrChunks = 0, nbrChunksOpt = 0;
   bool nbrValid = false;     // the lists describe pstar[pcur] as it is now
   bool omegaValid = false;   // pstar[2] holds the vorticity of the last extras pass (PBF_BUF_OMEGA), same order as the arrays
   // advance() path: the caller's std::vector<Particle> buffer, page-locked in place (hipHostRegister) so the per-frame
@@ -236,7 +238,10 @@ int ensure_particles(pbf_ctx *ctx, size_t n) {
   if (int rc = ensure(ctx, ctx->slotOf, n * 4)) return rc;
   if (int rc = ensure(ctx, ctx->qpos, (n + QPOS_PAD) * 8)) return rc;
   if (int rc = ensure(ctx, ctx->nbrCount, n * 4)) return rc;
-  if (int rc = ensure(ctx, ctx->nbrList, ((n + BLOCK - 1) / BLOCK) * size_t(NBR_CAP) * BLOCK * 4)) return rc;
+  // two-tier lists: NBR_ROWS slots per particle in rows + a pool of NBR_EXTRA-slot chunks for the few longer lists
+  if (int rc = ensure(ctx, ctx->nbrList, ((n + BLOCK - 1) / BLOCK) * size_t(NBR_ROWS) * BLOCK * 4)) return rc;
+  ctx->nbrChunks = ctx->nbrChunksOpt ? ctx->nbrChunksOpt : uint32_t(n / 16 + 1024);  // (option "nbr_chunks": tests shrink the pool)
+  if (int rc = ensure(ctx, ctx->nbrExtra, size_t(ctx->nbrChunks) * NBR_EXTRA * 4)) return rc;
   ctx->cap = n;
   return PBF_OK;
 }
@@ -480,6 +485,22 @@ inline int other_pstar(const pbf_ctx *ctx) { return ctx->pcur == 2 ? ctx->cur : 
 // PBF_FLAG_NO_LDS always forces the plain per-particle global walk.
 enum GatherMode { GATHER_PLAIN = 0, GATHER_SAVE_LISTS = 1, GATHER_FROM_LISTS = 2 };
 
+// A zeroed word of brickCtl (the sort stage zeroes them all once per step) for ONE launch: the work ticket of a persistent
+// tile kernel, or the chunk allocator of a list build.  More launches than words since the last sort: re-arm.
+uint32_t *next_ticket(pbf_ctx *ctx) {
+  uint32_t *ctl = ctx->brickCtl.as<uint32_t>();
+  if (ctx->gatherSeq >= kTickets) {
+    (void)hipMemsetAsync(ctl + 1, 0, kTickets * 4, ctx->stream);
+    ctx->gatherSeq = 0;
+  }
+  return ctl + 1 + ctx->gatherSeq++;
+}
+// build = this launch WRITES the lists (takes a fresh chunk allocator)
+NbrLists nbr_lists(pbf_ctx *ctx, bool build) {
+  return NbrLists{ctx->nbrList.as<uint32_t>(), ctx->nbrCount.as<uint32_t>(), ctx->nbrExtra.as<uint32_t>(),
+                  build ? next_ticket(ctx) : nullptr, ctx->nbrChunks};
+}
+
 template <typename N, typename Op>
 int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, GatherMode mode = GATHER_PLAIN) {
   const uint32_t *key = ctx->key[ctx->cur].as<const uint32_t>();
@@ -502,13 +523,7 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
       uint32_t cap = ctx->tileCap ? std::min(ctx->tileCap, 65535u) : 2048u;  // list entries of a tiled brick are tile slots
       uint32_t *nl = ctx->nbrList.as<uint32_t>(), *nc = ctx->nbrCount.as<uint32_t>();
       uint32_t *ctl = ctx->brickCtl.as<uint32_t>();
-      auto ticket = [&]() -> uint32_t * {
-        if (ctx->gatherSeq >= kTickets) {  // more launches than tickets since the last sort: re-arm
-          (void)hipMemsetAsync(ctl + 1, 0, kTickets * 4, ctx->stream);
-          ctx->gatherSeq = 0;
-        }
-        return ctl + 1 + ctx->gatherSeq++;
-      };
+      auto ticket = [&]() -> uint32_t * { return next_ticket(ctx); };
       auto launch_dims = [&](const void *kernel, size_t lds, size_t &attrSet) {
         if (lds > attrSet) {
           (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
@@ -544,22 +559,22 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
     }
   }
   if (ctx->gatherKind == 1 || ctx->gatherKind == 3) {
-    uint32_t *nl = ctx->nbrList.as<uint32_t>(), *nc = ctx->nbrCount.as<uint32_t>();
     const dim3 g = grid_for(ctx->n), b(BLOCK);
-    auto from_lists = [&]() {  // the list-driven reader: one lane per particle, or (option "coop") a lane group per particle
+    auto from_lists = [&]() {
+      const NbrLists ls = nbr_lists(ctx, false);  // the list-driven reader: one lane per particle, or (option "coop") a lane group per particle
       if constexpr (Op::kTileable && Op::kFilter) {
         auto coop_grid = [&](int k) { return dim3(unsigned(std::max<size_t>(1, (ctx->n * k + BLOCK - 1) / BLOCK))); };
         switch (ctx->coop) {
-          case 2: hipLaunchKernelGGL((k_gather_from_lists_coop<N, Op, 2>), coop_grid(2), b, 0, ctx->stream, c, args, key, table, nl, nc); return;
-          case 4: hipLaunchKernelGGL((k_gather_from_lists_coop<N, Op, 4>), coop_grid(4), b, 0, ctx->stream, c, args, key, table, nl, nc); return;
-          case 8: hipLaunchKernelGGL((k_gather_from_lists_coop<N, Op, 8>), coop_grid(8), b, 0, ctx->stream, c, args, key, table, nl, nc); return;
+          case 2: hipLaunchKernelGGL((k_gather_from_lists_coop<N, Op, 2>), coop_grid(2), b, 0, ctx->stream, c, args, key, table, ls); return;
+          case 4: hipLaunchKernelGGL((k_gather_from_lists_coop<N, Op, 4>), coop_grid(4), b, 0, ctx->stream, c, args, key, table, ls); return;
+          case 8: hipLaunchKernelGGL((k_gather_from_lists_coop<N, Op, 8>), coop_grid(8), b, 0, ctx->stream, c, args, key, table, ls); return;
           default: break;
         }
       }
       if (ctx->pipeline < 0 ? sizeof(N) == 8 : ctx->pipeline != 0)
-        hipLaunchKernelGGL((k_gather_from_lists<N, Op, true>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
+        hipLaunchKernelGGL((k_gather_from_lists<N, Op, true>), g, b, 0, ctx->stream, c, args, key, table, ls);
       else
-        hipLaunchKernelGGL((k_gather_from_lists<N, Op, false>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
+        hipLaunchKernelGGL((k_gather_from_lists<N, Op, false>), g, b, 0, ctx->stream, c, args, key, table, ls);
     };
     if (mode == GATHER_FROM_LISTS) {
       from_lists();
@@ -573,29 +588,29 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
         }
         if (ctx->splitBuild == 8) {  // the op rides on the build
           // (staging depth 32 and four survivors per drain trip: measured best of 16 / 24 / 32 x 2 / 4 / 6 / 8)
-          hipLaunchKernelGGL((k_build_lists_op<N, Op, 4, 32, 4>), g, b, 0, ctx->stream, c, args, Op::src(args), qp, args.type, key, table, nl, nc);
+          hipLaunchKernelGGL((k_build_lists_op<N, Op, 4, 32, 4>), g, b, 0, ctx->stream, c, args, Op::src(args), qp, args.type, key, table, nbr_lists(ctx, true));
           LAUNCH_CHECK(ctx);
           return PBF_OK;
         }
         StageTimer tb(ctx, ST_BUILD);
         if (ctx->splitBuild == 4)
-          hipLaunchKernelGGL((k_build_lists_q<N, 2>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc);
+          hipLaunchKernelGGL((k_build_lists_q<N, 2>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nbr_lists(ctx, true));
         else  // staging depth (option "list_max", default 32: one flush for most particles beats the two more workgroups per CU that 16 leaves room for: -2 % per step)
           switch (ctx->listMax ? ctx->listMax : 32u) {
-            case 16: hipLaunchKernelGGL((k_build_lists_q<N, 4, 16>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc); break;
-            case 24: hipLaunchKernelGGL((k_build_lists_q<N, 4, 24>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc); break;
-            default: hipLaunchKernelGGL((k_build_lists_q<N, 4, 32>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nl, nc); break;
+            case 16: hipLaunchKernelGGL((k_build_lists_q<N, 4, 16>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nbr_lists(ctx, true)); break;
+            case 24: hipLaunchKernelGGL((k_build_lists_q<N, 4, 24>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nbr_lists(ctx, true)); break;
+            default: hipLaunchKernelGGL((k_build_lists_q<N, 4, 32>), g, b, 0, ctx->stream, c, Op::src(args), qp, args.type, key, table, nbr_lists(ctx, true)); break;
           }
       }
       from_lists();
     } else if (mode == GATHER_SAVE_LISTS) {
-      hipLaunchKernelGGL((k_gather_lists<N, Op, 16, true>), g, b, 0, ctx->stream, c, args, key, table, nl, nc);
+      hipLaunchKernelGGL((k_gather_lists<N, Op, 16, true>), g, b, 0, ctx->stream, c, args, key, table, nbr_lists(ctx, true));
     } else {
       switch (ctx->listMax ? ctx->listMax : 16u) {
-        case 12: hipLaunchKernelGGL((k_gather_lists<N, Op, 12>), g, b, 0, ctx->stream, c, args, key, table, nl, nc); break;
-        case 24: hipLaunchKernelGGL((k_gather_lists<N, Op, 24>), g, b, 0, ctx->stream, c, args, key, table, nl, nc); break;
-        case 32: hipLaunchKernelGGL((k_gather_lists<N, Op, 32>), g, b, 0, ctx->stream, c, args, key, table, nl, nc); break;
-        default: hipLaunchKernelGGL((k_gather_lists<N, Op, 16>), g, b, 0, ctx->stream, c, args, key, table, nl, nc); break;
+        case 12: hipLaunchKernelGGL((k_gather_lists<N, Op, 12>), g, b, 0, ctx->stream, c, args, key, table, nbr_lists(ctx, false)); break;
+        case 24: hipLaunchKernelGGL((k_gather_lists<N, Op, 24>), g, b, 0, ctx->stream, c, args, key, table, nbr_lists(ctx, false)); break;
+        case 32: hipLaunchKernelGGL((k_gather_lists<N, Op, 32>), g, b, 0, ctx->stream, c, args, key, table, nbr_lists(ctx, false)); break;
+        default: hipLaunchKernelGGL((k_gather_lists<N, Op, 16>), g, b, 0, ctx->stream, c, args, key, table, nbr_lists(ctx, false)); break;
       }
     }
     LAUNCH_CHECK(ctx);
@@ -686,17 +701,17 @@ template <typename N> int stage_lambda(pbf_ctx *ctx, const pbf_params *p) {
     typename DiffuseOp<N>::Args xa{ctx->col4[s].as<const vec4<N>>(), ctx->col4[d].as<vec4<N>>(),
                                    ctx->type[s].as<const uint8_t>()};
     const uint32_t *key = ctx->key[s].as<const uint32_t>(), *table = ctx->table.as<const uint32_t>();
-    uint32_t *nl = ctx->nbrList.as<uint32_t>(), *nc = ctx->nbrCount.as<uint32_t>();
+    const NbrLists ls = nbr_lists(ctx, true);
     if (ctx->fast) {
       typename LambdaOp<N, true>::Args a{ctx->pstar[ctx->pcur].as<vec4<N>>(), ctx->pos4[s].as<const vec4<N>>(),
                                          ctx->type[s].as<const uint8_t>()};
       hipLaunchKernelGGL((k_gather_lists<N, LambdaOp<N, true>, 16, true, DiffuseOp<N>>), grid_for(ctx->n), dim3(BLOCK), 0,
-                         ctx->stream, c, a, key, table, nl, nc, xa);
+                         ctx->stream, c, a, key, table, ls, xa);
     } else {
       typename LambdaOp<N, false>::Args a{ctx->pstar[ctx->pcur].as<vec4<N>>(), ctx->pos4[s].as<const vec4<N>>(),
                                           ctx->type[s].as<const uint8_t>()};
       hipLaunchKernelGGL((k_gather_lists<N, LambdaOp<N, false>, 16, true, DiffuseOp<N>>), grid_for(ctx->n), dim3(BLOCK), 0,
-                         ctx->stream, c, a, key, table, nl, nc, xa);
+                         ctx->stream, c, a, key, table, ls, xa);
     }
     LAUNCH_CHECK(ctx);
     std::swap(ctx->col4[s], ctx->col4[d]);
@@ -928,6 +943,10 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   else if (n == "fuse_predict") ctx->fusePredict = value != 0;
   else if (n == "timing_mask") ctx->timingMask = uint32_t(value);
   else if (n == "pad_lds") ctx->padLds = uint32_t(value);
+  else if (n == "nbr_chunks") {  // diagnostic: size of the lists' second tier (before the first upload; 0 = capacity / 16 + 1024)
+    if (ctx->cap) return fail(ctx, PBF_ERR_STATE, "nbr_chunks must be set before the first upload");
+    ctx->nbrChunksOpt = uint32_t(value);
+  }
   else return fail(ctx, PBF_ERR_INVALID, "unknown option " + n);
   return PBF_OK;
 }
@@ -1020,7 +1039,7 @@ void pbf_destroy(pbf_ctx *ctx) {
                    &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2], &ctx->count, &ctx->table,   &ctx->blockSums,
                    &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl, &ctx->bigCells,
                    &ctx->latticePN, &ctx->latticeC, &ctx->mcCounts, &ctx->mcOffsets, &ctx->mcSums, &ctx->meshV, &ctx->meshN,
-                   &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR, &ctx->colHist, &ctx->wireSend[0], &ctx->wireSend[1], &ctx->wireRecv[0], &ctx->wireRecv[1], &ctx->diffSum, &ctx->diffCnt};
+                   &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->nbrExtra, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR, &ctx->colHist, &ctx->wireSend[0], &ctx->wireSend[1], &ctx->wireRecv[0], &ctx->wireRecv[1], &ctx->diffSum, &ctx->diffCnt};
   for (DevBuf *b : all)
     if (b->p) (void)hipFree(b->p);
   for (auto &g : ctx->graphs)
@@ -1354,6 +1373,19 @@ int pbf_selftest_math(pbf_ctx *ctx, uint64_t mismatches[4]) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (int rc = ensure(ctx, ctx->selTotals, 64)) return rc;
   HIPCHK(ctx, hipMemsetAsync(ctx->selTotals.p, 0, 32, ctx->stream));
+  if (ctx->fp64) {  // 1.07e10 pseudo-random operands per category and run (exhaustive is impossible in fp64): 2^20 threads x 10240
+    const double h = ctx->desc.h;
+    const double p6 = poly6_factor<double>(h), r = double(CorrDeltaQ * h), d = (h * h) - r * r;
+    const uint32_t rounds = 10240, blocks = 4096;
+    hipLaunchKernelGGL(k_selftest_math64, dim3(blocks), dim3(BLOCK), 0, ctx->stream, ctx->selTotals.as<unsigned long long>(),
+                       p6 * (d * d * d), double(RHO), h, rounds);
+    LAUNCH_CHECK(ctx);
+    unsigned long long hst[4] = {0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(hst, ctx->selTotals.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 4; ++k) mismatches[k] = hst[k];
+    return PBF_OK;
+  }
   // the two per-launch constant divisors of delta-p for this context's h: poly6(0.3 h) and the reference density
   const float h = float(ctx->desc.h);
   const float p6 = poly6_factor<float>(h), r = float(CorrDeltaQ * h), d = (h * h) - r * r;

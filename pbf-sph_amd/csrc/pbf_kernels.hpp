@@ -447,10 +447,27 @@ __device__ inline float sqrt_rsq(float x, float &y) {
   const float g = x * y, hy = 0.5f * y;
   return fmaf(fmaf(-g, g, x), hy, g);
 }
+// fp64 (round 3): hipcc's IEEE sqrt(double) is v_rsq_f64 + one coupled Goldschmidt step + two residual corrections
+// (7 fma, 2 mul) inside a 2^256 rescale for x < 2^-767 (compare, two selects, two v_ldexp) and a class test with two more
+// selects: 18 VALU.  The pair terms only ever feed it d2 >= 0, so the trimmed form below executes the VERY SAME arithmetic
+// instructions without the wrappers — bit-identical BY CONSTRUCTION wherever the rescale is the identity (x >= 2^-767) —
+// in 10 VALU, and hands out y ~ 1 / sqrt(x) (2 h, relative error ~2^-51) as a by-product.  The addend 2^-600 keeps x = 0 (a
+// particle meeting itself) away from v_rsq's infinity and is absorbed exactly by every x >= 2^-547; below that
+// (r < 2^-273, far under EPSILON) every small r yields the same pair terms.  An exhaustive sweep is impossible in fp64:
+// k_selftest_math64 compares > 10^10 pseudo-random operands (whole exponent range + the pair terms' own range, densely)
+// with the compiler's forms — pbf_selftest_math on an fp64 context.
 __device__ inline double sqrt_rsq(double x, double &y) {
-  const double r = sqrt(x);
-  y = 1.0 / r;
-  return r;
+  x += 0x1p-600;
+  const double r = __builtin_amdgcn_rsq(x);
+  double g = x * r, hh = r * 0.5;
+  const double e = fma(-hh, g, 0.5);
+  g = fma(g, e, g), hh = fma(hh, e, hh);
+  double d = fma(-g, g, x);
+  g = fma(d, hh, g);
+  d = fma(-g, g, x);
+  g = fma(d, hh, g);
+  y = hh + hh;
+  return g;
 }
 __device__ inline float div_seeded(float a, float b, float y) {
   y = fmaf(fmaf(-b, y, 1.0f), y, y);
@@ -458,12 +475,30 @@ __device__ inline float div_seeded(float a, float b, float y) {
   return fmaf(fmaf(-b, q, a), y, q);  // ONE residual correction: relative error ~2^-47 before the final rounding — enough
                                       // for every operand the sweeps visit (k_selftest_math), which is every operand used
 }
-__device__ inline double div_seeded(double a, double b, double) { return a / b; }
+// a / b in fp64 from a seed y ~ 1 / b: hipcc's IEEE divide is v_div_scale x 2, v_rcp_f64, two Newton steps on the
+// reciprocal, the quotient, its exact residual (fma) and one correction (v_div_fmas), then v_div_fixup: 11 VALU, two of
+// them quarter-rate.  With operands in the pair terms' range nothing needs scaling or fixing.  Error-bound argument for the
+// form below (Markstein 1990; Muller et al., Handbook of FP Arithmetic, thm. "correcting a quotient with an fma"): let y1 be
+// the refined reciprocal, |y1 - 1/b| <= (1/2 + 2^-40) ulp(1/b) (y0 carries <= 2^-26 — v_rcp_f64 — or ~2^-51 — the by-product
+// of sqrt_rsq — so NEWTON steps leave (2^-26)^(2^NEWTON) resp. 2^-102 of it plus one rounding), q0 = RN(a y1) is then within 1 ulp of
+// a / b, res = a - b q0 is EXACT in one fma (Sterbenz-type cancellation), and q0 + res y1 differs from a / b by less than
+// 2^-52 ulp(q0) — below half the smallest distance between a quotient of two doubles and a rounding boundary whenever y1
+// is the correctly rounded reciprocal, which the sweep checks rather than assumes: mismatches against the compiler's divide
+// over > 10^10 operands must be ZERO (k_selftest_math64).
+template <int NEWTON> __device__ inline double div_newton(double a, double b, double y) {
+#pragma unroll
+  for (int k = 0; k < NEWTON; ++k) y = fma(y, fma(-b, y, 1.0), y);
+  const double q = a * y;
+  return fma(fma(-b, q, a), y, q);
+}
+__device__ inline double div_seeded(double a, double b, double y) { return div_newton<1>(a, b, y); }  // seed: sqrt_rsq's y
 __device__ inline float div_ranged(float a, float b) { return div_seeded(a, b, __builtin_amdgcn_rcpf(b)); }
-__device__ inline double div_ranged(double a, double b) { return a / b; }
+// divisor = a per-launch constant: the reciprocal and its two Newton steps are loop-invariant (hoisted), 3 fma / mul remain
+__device__ inline double div_ranged(double a, double b) { return div_newton<2>(a, b, __builtin_amdgcn_rcp(b)); }
 // The numerators div_ranged is the IEEE divide for: finite and at least 2^-100 in magnitude (x * 0 + x turns an
 // infinity into a NaN, which fails the compare like a NaN, a zero or a tiny numerator does)
 __device__ inline bool div_ranged_ok(float x) { return fabsf(fmaf(x, 0.0f, x)) >= 0x1p-100f; }
+__device__ inline bool div_ranged_ok(double x) { return fabs(fma(x, 0.0, x)) >= 0x1p-700; }  // (no scaling by v_div_scale)
 
 template <typename N, bool FAST>
 __device__ inline PairGeom<N, FAST> pair_geom(const vec4<N> &a, const vec4<N> &b, N h) {
@@ -655,7 +690,7 @@ template <typename N, bool FAST> struct DeltaOp {
   // (lambda_a + lambda_b + corr) / RHO: the trimmed divide where it IS the IEEE one (div_ranged_ok), the compiler's
   // otherwise — decided per wave, so the common path carries one fma and one compare and no divergence
   __device__ static N over_rho(N num) {
-    if constexpr (FAST || sizeof(N) == 8) {
+    if constexpr (FAST) {
       return num / N(RHO);
     } else {
       if (__builtin_expect(__any(!div_ranged_ok(num)), 0)) return num / N(RHO);
@@ -1087,8 +1122,56 @@ __global__ __launch_bounds__(BLOCK) void k_diffuse_apply(StepConsts<N> c, typena
 // coalesced 1 KiB rows (measured: [particle][slot] rows cost +50 % in the reader and more in the
 // writer; whole padded rows overflow — lanes fill at different times); at most NBR_CAP slots per
 // particle, a particle with more survivors is marked NBR_OVERFLOW and walks.
-constexpr uint32_t NBR_CAP = 64;
+// Two tiers (round 3; the settled dam-break's lists: mean 31, p99 41-44, 1.3 % (1 M) / 4 % (4 M) of the particles above 40
+// — profiles/r03_list_hist.json): the [block][slot][thread] rows hold the first NBR_ROWS = 40 slots of every particle, a
+// particle with more takes ONE chunk of NBR_EXTRA = 24 further slots from a pool (an atomic ticket per such particle and
+// launch; pool = capacity / 16 chunks), 64 slots in all as before.  170 instead of 260 bytes of list per particle (-35 %);
+// a particle beyond 64, or one that finds the pool empty, is marked NBR_OVERFLOW and walks its cells in the readers.
+constexpr uint32_t NBR_ROWS = 40, NBR_EXTRA = 24, NBR_CAP = NBR_ROWS + NBR_EXTRA;
 constexpr uint32_t NBR_OVERFLOW = 0xFFFFFFFFu;
+constexpr uint32_t NBR_NO_CHUNK = 0xFFFFFFFFu;
+static_assert(NBR_ROWS % 4 == 0 && NBR_EXTRA % 4 == 0 && NBR_CAP < 256, "readers take 4 entries per trip; the length lives in 8 bits");
+struct NbrLists {
+  uint32_t *rows;    // [block][NBR_ROWS][BLOCK]
+  uint32_t *count;   // per particle: length | chunk << 8 (chunk only meaningful when length > NBR_ROWS), or NBR_OVERFLOW
+  uint32_t *extra;   // [chunk][NBR_EXTRA]
+  uint32_t *ticket;  // this launch's chunk allocator: a word that is zero when the launch starts
+  uint32_t chunks;   // chunks in the pool
+};
+// one particle's list as its lane writes it, slot by slot in walk order
+struct NbrWriter {
+  uint32_t *row;     // this lane's column of its block's rows
+  uint32_t chunk = NBR_NO_CHUNK;
+  __device__ NbrWriter(const NbrLists &l, uint32_t block, uint32_t tid) : row(l.rows + size_t(block) * NBR_ROWS * BLOCK + tid) {}
+  __device__ void put(const NbrLists &l, uint32_t slot, uint32_t b) {
+    if (slot < NBR_ROWS) {
+      row[slot * BLOCK] = b;
+    } else if (slot < NBR_CAP) {
+      if (chunk == NBR_NO_CHUNK) chunk = atomicAdd(l.ticket, 1u);
+      if (chunk < l.chunks) l.extra[size_t(chunk) * NBR_EXTRA + (slot - NBR_ROWS)] = b;
+    }
+  }
+  __device__ uint32_t finish(const NbrLists &l, uint32_t written) const {
+    if (written <= NBR_ROWS) return written;
+    return (written <= NBR_CAP && chunk < l.chunks) ? (written | (chunk << 8)) : NBR_OVERFLOW;
+  }
+};
+// ... and as a reader sees it
+struct NbrReader {
+  const uint32_t *row, *extra;
+  uint32_t cnt;  // NBR_OVERFLOW: walk
+  __device__ NbrReader(const NbrLists &l, uint32_t i) {
+    const uint32_t raw = l.count[i];
+    row = l.rows + size_t(i / BLOCK) * NBR_ROWS * BLOCK + (i % BLOCK);
+    cnt = raw == NBR_OVERFLOW ? raw : (raw & 0xFFu);
+    extra = l.extra + size_t(raw == NBR_OVERFLOW || (raw & 0xFFu) <= NBR_ROWS ? 0u : raw >> 8) * NBR_EXTRA;
+  }
+  // any slot (the pipelined / cooperative readers); slots past the list are clamped into it and their entries discarded
+  __device__ uint32_t entry(uint32_t slot) const {
+    slot = min(slot, NBR_CAP - 1u);
+    return slot < NBR_ROWS ? row[slot * BLOCK] : extra[slot - NBR_ROWS];
+  }
+};
 
 // A second, unfiltered op can ride along on the same walk (FUSE_DIFFUSE: the colour diffusion needs
 // exactly the candidates the first lambda launch of a step visits, in the same order).
@@ -1099,8 +1182,7 @@ template <typename N, typename Op, int LMAX, bool SAVE = false, typename Extra =
 __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typename Op::Args args,
                                                         const uint32_t *__restrict__ key,
                                                         const uint32_t *__restrict__ table,
-                                                        uint32_t *__restrict__ nbrList,
-                                                        uint32_t *__restrict__ nbrCount,
+                                                        NbrLists lists,
                                                         typename Extra::Args xargs = {}) {
   constexpr bool FUSED = !std::is_same<Extra, NoExtra>::value;
   __shared__ uint32_t list[(Op::kFilter ? LMAX + 4 : 1) * BLOCK];  // +4: a trip appends up to WAYS past LMAX - 1
@@ -1116,19 +1198,19 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
   Extra extra;
   if constexpr (FUSED) extra.begin(c, xargs, i);  // skips exactly when op.begin() does (type != 0) and copies through
   if (!op.begin(c, args, i)) {
-    if (SAVE) nbrCount[i] = 0;
+    if (SAVE) lists.count[i] = 0;
     return;
   }
   // From here on control flow is WAVE-UNIFORM over the lanes that are left (loop conditions are
   // __any votes): every drain is executed by all of them together.
   uint32_t nl = 0, written = 0;
-  uint32_t *mine = SAVE ? nbrList + size_t(chunk) * NBR_CAP * BLOCK + tid : nullptr;
+  NbrWriter wr(lists, chunk, tid);
   auto drain = [&]() {
 #pragma unroll 2
     for (uint32_t q = 0; __any(q < nl); ++q) {
       const bool valid = q < nl;
       const uint32_t b = valid ? list[q * BLOCK + tid] : i;
-      if (SAVE && valid && written + q < NBR_CAP) mine[(written + q) * BLOCK] = b;
+      if (SAVE && valid) wr.put(lists, written + q, b);
       op.add_bf(c, Op::load(args, b), valid);
     }
     written += nl;
@@ -1179,7 +1261,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
       }
     }
   drain();
-  if (SAVE) nbrCount[i] = written <= NBR_CAP ? written : NBR_OVERFLOW;
+  if (SAVE) lists.count[i] = wr.finish(lists, written);
   op.end(c, args, i);
   if constexpr (FUSED) extra.end(c, xargs, i);
 }
@@ -1234,8 +1316,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const 
                                                          const uint8_t *__restrict__ type,
                                                          const uint32_t *__restrict__ key,
                                                          const uint32_t *__restrict__ table,
-                                                         uint32_t *__restrict__ nbrList,
-                                                         uint32_t *__restrict__ nbrCount) {
+                                                         NbrLists lists) {
   static_assert(4 * W + 2 <= QPOS_PAD, "qpos padding");
   __shared__ uint32_t list[(LMAX + 2 * W) * BLOCK];  // per-lane staging: a trip appends up to 2 W past LMAX - 1
   const uint32_t tid = threadIdx.x;
@@ -1243,7 +1324,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const 
   const uint32_t i = chunk * BLOCK + tid;
   if (i >= c.n) return;
   if (c.hasObstacles && type[i] != 0) {
-    nbrCount[i] = 0;
+    lists.count[i] = 0;
     return;
   }
   // 32-bit byte offsets from uniform bases: one shift per address
@@ -1256,11 +1337,11 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const 
     const qpair dxy = __builtin_bit_cast(qpair, qx) - axy, dzw = __builtin_bit_cast(qpair, qy) - azw;
     return uint32_t(qdot2(__builtin_bit_cast(uint32_t, dzw), qdot2(__builtin_bit_cast(uint32_t, dxy)))) <= t2;
   };
-  uint32_t *blk = nbrList + size_t(chunk) * NBR_CAP * BLOCK;
+  NbrWriter wr(lists, chunk, tid);
   uint32_t written = 0, nl = 0;
   auto flush = [&]() {
     for (uint32_t q = 0; __any(q < nl); ++q)
-      if (q < nl && written + q < NBR_CAP) blk[(written + q) * BLOCK + tid] = list[q * BLOCK + tid];
+      if (q < nl) wr.put(lists, written + q, list[q * BLOCK + tid]);
     written += nl;
     nl = 0;
   };
@@ -1322,7 +1403,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const 
     }
   }
   flush();
-  nbrCount[i] = written <= NBR_CAP ? written : NBR_OVERFLOW;
+  lists.count[i] = wr.finish(lists, written);
 }
 
 // The same build with an op riding on it (option split_build = 8): the survivors staged in LDS are not only flushed to
@@ -1335,8 +1416,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_op(StepConsts<N> c, typen
                                                          const uint8_t *__restrict__ type,
                                                          const uint32_t *__restrict__ key,
                                                          const uint32_t *__restrict__ table,
-                                                         uint32_t *__restrict__ nbrList,
-                                                         uint32_t *__restrict__ nbrCount) {
+                                                         NbrLists lists) {
   static_assert(4 * W + 2 <= QPOS_PAD, "qpos padding");
   __shared__ uint32_t list[(LMAX + 2 * W) * BLOCK];  // per-lane staging: a trip appends up to 2 W past LMAX - 1
   const uint32_t tid = threadIdx.x;
@@ -1345,7 +1425,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_op(StepConsts<N> c, typen
   if (i >= c.n) return;
   Op op;
   if (!op.begin(c, args, i)) {  // (obstacles, ghosts: the op has stored what it owes them)
-    nbrCount[i] = 0;
+    lists.count[i] = 0;
     return;
   }
   // 32-bit byte offsets from uniform bases: one shift per address
@@ -1358,7 +1438,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_op(StepConsts<N> c, typen
     const qpair dxy = __builtin_bit_cast(qpair, qx) - axy, dzw = __builtin_bit_cast(qpair, qy) - azw;
     return uint32_t(qdot2(__builtin_bit_cast(uint32_t, dzw), qdot2(__builtin_bit_cast(uint32_t, dxy)))) <= t2;
   };
-  uint32_t *blk = nbrList + size_t(chunk) * NBR_CAP * BLOCK;
+  NbrWriter wr(lists, chunk, tid);
   uint32_t written = 0, nl = 0;
   auto flush = [&]() {
     for (uint32_t q = 0; __any(q < nl); q += FW) {  // FW survivors per trip: their gathers and pair terms interleave
@@ -1370,7 +1450,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_op(StepConsts<N> c, typen
       for (uint32_t w = 0; w < FW; ++w) cnd[w] = Op::load(args, b[w]);
 #pragma unroll
       for (uint32_t w = 0; w < FW; ++w)
-        if (q + w < nl && written + q + w < NBR_CAP) blk[(written + q + w) * BLOCK + tid] = b[w];
+        if (q + w < nl) wr.put(lists, written + q + w, b[w]);
 #pragma unroll
       for (uint32_t w = 0; w < FW; ++w) op.add_bf(c, cnd[w], q + w < nl);
     }
@@ -1435,7 +1515,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_op(StepConsts<N> c, typen
     }
   }
   flush();
-  nbrCount[i] = written <= NBR_CAP ? written : NBR_OVERFLOW;
+  lists.count[i] = wr.finish(lists, written);
   op.end(c, args, i);
 }
 
@@ -1461,21 +1541,20 @@ template <typename N, typename Op, bool PIPELINED = true>
 __global__ __launch_bounds__(BLOCK) void k_gather_from_lists(StepConsts<N> c, typename Op::Args args,
                                                              const uint32_t *__restrict__ key,
                                                              const uint32_t *__restrict__ table,
-                                                             const uint32_t *__restrict__ nbrList,
-                                                             const uint32_t *__restrict__ nbrCount) {
+                                                             NbrLists lists) {
   const uint32_t tid = threadIdx.x;
   const uint32_t chunk = xcd_chunk();
   const uint32_t i = chunk * BLOCK + tid;
   if (i >= c.n) return;
   Op op;
   if (!op.begin(c, args, i)) return;
-  const uint32_t cnt = nbrCount[i];
-  const uint32_t *mine = nbrList + size_t(chunk) * NBR_CAP * BLOCK + tid;
+  const NbrReader rd(lists, i);
+  const uint32_t cnt = rd.cnt;
   if (cnt == NBR_OVERFLOW) {
     for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { op.add(c, Op::load(args, b)); });
   } else if constexpr (PIPELINED) {
     constexpr uint32_t W = sizeof(N) == 4 ? 4 : 2;
-    auto entry = [&](uint32_t slot) { return mine[min(slot, NBR_CAP - 1u) * BLOCK]; };
+    auto entry = [&](uint32_t slot) { return rd.entry(slot); };
     uint32_t e1[W];           // raw list entries of trip t + 1
     typename Op::Src cur[W];  // candidates of trip t
 #pragma unroll
@@ -1502,15 +1581,27 @@ __global__ __launch_bounds__(BLOCK) void k_gather_from_lists(StepConsts<N> c, ty
       }
     }
   } else {
-    for (uint32_t q = 0; q < cnt; q += 4) {  // four list entries and their candidates in flight per trip
+    // the rows' part of the list, then — for the few particles that have one — the chunk's (same order: slots 0 .. cnt - 1)
+    const uint32_t head = min(cnt, NBR_ROWS), tail = cnt - head;
+    for (uint32_t q = 0; q < head; q += 4) {  // four list entries and their candidates in flight per trip
       uint32_t b[4];
       typename Op::Src cnd[4];
 #pragma unroll
-      for (uint32_t w = 0; w < 4; ++w) b[w] = q + w < cnt ? mine[(q + w) * BLOCK] : i;
+      for (uint32_t w = 0; w < 4; ++w) b[w] = q + w < head ? rd.row[(q + w) * BLOCK] : i;
 #pragma unroll
       for (uint32_t w = 0; w < 4; ++w) cnd[w] = Op::load(args, b[w]);
 #pragma unroll
-      for (uint32_t w = 0; w < 4; ++w) op.add_bf(c, cnd[w], q + w < cnt);
+      for (uint32_t w = 0; w < 4; ++w) op.add_bf(c, cnd[w], q + w < head);
+    }
+    for (uint32_t q = 0; q < tail; q += 4) {
+      uint32_t b[4];
+      typename Op::Src cnd[4];
+#pragma unroll
+      for (uint32_t w = 0; w < 4; ++w) b[w] = q + w < tail ? rd.extra[q + w] : i;
+#pragma unroll
+      for (uint32_t w = 0; w < 4; ++w) cnd[w] = Op::load(args, b[w]);
+#pragma unroll
+      for (uint32_t w = 0; w < 4; ++w) op.add_bf(c, cnd[w], q + w < tail);
     }
   }
   op.end(c, args, i);
@@ -1527,8 +1618,7 @@ template <typename N, typename Op, int COOP>
 __global__ __launch_bounds__(BLOCK) void k_gather_from_lists_coop(StepConsts<N> c, typename Op::Args args,
                                                                   const uint32_t *__restrict__ key,
                                                                   const uint32_t *__restrict__ table,
-                                                                  const uint32_t *__restrict__ nbrList,
-                                                                  const uint32_t *__restrict__ nbrCount) {
+                                                                  NbrLists lists) {
   static_assert(COOP == 2 || COOP == 4 || COOP == 8, "group size");
   constexpr uint32_t PER_BLOCK = BLOCK / COOP;  // particles per workgroup
   const uint32_t sub = threadIdx.x % COOP;
@@ -1539,14 +1629,14 @@ __global__ __launch_bounds__(BLOCK) void k_gather_from_lists_coop(StepConsts<N> 
   bool active = false;
   if (live) active = op.begin(c, args, i);  // every lane of the group loads the particle (same addresses: one request)
   if (active) {
-    const uint32_t cnt = nbrCount[i];
+    const NbrReader rd(lists, i);
+    const uint32_t cnt = rd.cnt;
     if (cnt == NBR_OVERFLOW) {
       if (sub == 0) for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { op.add(c, Op::load(args, b)); });
     } else {
-      const uint32_t *mine = nbrList + size_t(i / BLOCK) * NBR_CAP * BLOCK + (i % BLOCK);
       for (uint32_t q = sub; q < cnt; q += 2 * COOP) {  // two entries of this lane's share in flight per trip
         const uint32_t q1 = q + COOP;
-        const uint32_t b0 = mine[q * BLOCK], b1 = q1 < cnt ? mine[q1 * BLOCK] : i;
+        const uint32_t b0 = rd.entry(q), b1 = q1 < cnt ? rd.entry(q1) : i;
         const typename Op::Src c0 = Op::load(args, b0), c1 = Op::load(args, b1);
         op.add_bf(c, c0, true);
         op.add_bf(c, c1, q1 < cnt);
@@ -1683,6 +1773,72 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_math(unsigned long long *__r
       badA += mid && ((qa != qa) ? !(ra != ra) : __float_as_int(qa) != __float_as_int(ra));
       const float rb = x / divisorB, qb = div_ranged_ok(x) ? div_ranged(x, divisorB) : rb;
       badB += (qb != qb) ? !(rb != rb) : __float_as_int(qb) != __float_as_int(rb);
+    }
+  }
+  if (badSqrt) atomicAdd(&bad[0], badSqrt);
+  if (badDiv) atomicAdd(&bad[1], badDiv);
+  if (badA) atomicAdd(&bad[2], badA);
+  if (badB) atomicAdd(&bad[3], badB);
+}
+
+// The fp64 counterpart: an exhaustive sweep is impossible (2^64 operands), so `rounds` x gridDim x BLOCK pseudo-random
+// operands per category (splitmix64 of a global counter: reproducible), drawn so that every binade of the stated range is hit
+// equally often and the pair terms' own operand ranges densely:
+//   bad[0]  sqrt_rsq(x) vs sqrt(x): x = 2^e m, e uniform in [-540, 500] (half of the draws) or d2 of a pair: r uniform in
+//           (0, 2 h) (the other half);
+//   bad[1]  div_seeded((h - r)^2, r, y) vs the IEEE quotient, r = sqrt(d2) in [1e-8, h] (r uniform, and log-uniform), y the
+//           by-product of sqrt_rsq(d2) — exactly the operands pair_geom hands it — for the context's h and three more;
+//   bad[2]  div_ranged(x, poly6(0.3 h)) vs x / poly6(0.3 h): |x| log-uniform in [1e-60, 1e30], both signs;
+//   bad[3]  DeltaOp's x / RHO — div_ranged where div_ranged_ok(x), the compiler's divide otherwise — |x| = 2^e m with e
+//           uniform over [-1070, 1000] (denormals included), both signs.
+__device__ inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ inline double unit53(uint64_t u) { return double(u >> 11) * 0x1p-53; }                 // [0, 1)
+__device__ inline double pow2_times_mantissa(uint64_t u, int elo, int ehi) {                       // 2^e m, m in [1, 2)
+  const int e = elo + int((u >> 52) % uint64_t(ehi - elo + 1));
+  return ldexp(1.0 + double(u & 0xFFFFFFFFFFFFFull) * 0x1p-52, e);
+}
+__global__ __launch_bounds__(BLOCK) void k_selftest_math64(unsigned long long *__restrict__ bad, double divisorA,
+                                                           double divisorB, double hOwn, uint32_t rounds) {
+  unsigned long long badSqrt = 0, badDiv = 0, badA = 0, badB = 0;
+  const double hs[4] = {hOwn, 0.05, 0.2, 0.0999999};
+  const uint64_t tid = uint64_t(blockIdx.x) * BLOCK + threadIdx.x, stride = uint64_t(gridDim.x) * BLOCK;
+  for (uint32_t k = 0; k < rounds; ++k) {
+    const uint64_t u0 = splitmix64((tid + k * stride) * 4u), u1 = splitmix64(u0), u2 = splitmix64(u1), u3 = splitmix64(u2);
+    {
+      double x;
+      if (u0 & 1u) x = pow2_times_mantissa(u1, -540, 500);
+      else {
+        const double r = unit53(u1) * 2.0 * hOwn;
+        x = r * r;
+      }
+      double y;
+      badSqrt += __double_as_longlong(sqrt_rsq(x, y)) != __double_as_longlong(sqrt(x));
+    }
+    {
+      const double hk = hs[(u0 >> 1) & 3u];
+      double r = (u0 & 8u) ? unit53(u2) * hk : exp2(-26.5 + unit53(u2) * 26.5) * hk;  // uniform / log-uniform in (~1e-8 h, h)
+      const double d2 = r * r;
+      double y;
+      const double root = sqrt_rsq(d2, y);
+      if (root >= 1e-8 && root <= hk) {
+        const double hr = hk - root, num = hr * hr;
+        badDiv += __double_as_longlong(div_seeded(num, root, y)) != __double_as_longlong(num / root);
+      }
+    }
+    {
+      double x = exp2(-199.3 + unit53(u3) * 299.0);  // 1e-60 .. 1e30
+      if (u3 & 1u) x = -x;
+      const double qa = div_ranged(x, divisorA), ra = x / divisorA;
+      badA += __double_as_longlong(qa) != __double_as_longlong(ra);
+      double z = pow2_times_mantissa(splitmix64(u3), -1070, 1000);
+      if (u3 & 2u) z = -z;
+      const double rb = z / divisorB, qb = div_ranged_ok(z) ? div_ranged(z, divisorB) : rb;
+      badB += __double_as_longlong(qb) != __double_as_longlong(rb);
     }
   }
   if (badSqrt) atomicAdd(&bad[0], badSqrt);

@@ -84,10 +84,10 @@ __device__ inline uint32_t tile_home_cell(uint32_t k) {
 }
 
 __device__ inline uint32_t *nbr_row(uint32_t *nbrList, uint32_t i) {
-  return nbrList + size_t(i / BLOCK) * NBR_CAP * BLOCK + (i % BLOCK);
+  return nbrList + size_t(i / BLOCK) * NBR_ROWS * BLOCK + (i % BLOCK);
 }
 __device__ inline const uint32_t *nbr_row(const uint32_t *nbrList, uint32_t i) {
-  return nbrList + size_t(i / BLOCK) * NBR_CAP * BLOCK + (i % BLOCK);
+  return nbrList + size_t(i / BLOCK) * NBR_ROWS * BLOCK + (i % BLOCK);
 }
 
 // One particle's list with global loads and a store per hit: the same list k_build_lists_q writes (global indices, walk
@@ -111,11 +111,11 @@ __device__ inline void build_one_plain(const StepConsts<N> &c, const vec4<N> *__
     const uint2 q = qpos[b];
     const qpair dxy = __builtin_bit_cast(qpair, q.x) - axy, dzw = __builtin_bit_cast(qpair, q.y) - azw;
     if (uint32_t(qdot2(__builtin_bit_cast(uint32_t, dzw), qdot2(__builtin_bit_cast(uint32_t, dxy)))) <= t2) {
-      if (written < NBR_CAP) row[written * BLOCK] = b;
+      if (written < NBR_ROWS) row[written * BLOCK] = b;
       ++written;
     }
   });
-  nbrCount[i] = written <= NBR_CAP ? written : NBR_OVERFLOW;
+  nbrCount[i] = written <= NBR_ROWS ? written : NBR_OVERFLOW;
 }
 
 // One particle's op from a row of GLOBAL indices (the serial form of k_gather_from_lists)
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_build(StepConsts<N> c, co
       auto flush = [&]() {
         for (uint32_t q = 0; __any(q < cur); q += SLOT) {
           const uint32_t k = written + q / SLOT;
-          if (q < cur && k < NBR_CAP) row[k * BLOCK] = *reinterpret_cast<const uint16_t *>(lbase + q);
+          if (q < cur && k < NBR_ROWS) row[k * BLOCK] = *reinterpret_cast<const uint16_t *>(lbase + q);
         }
         written += cur / SLOT;
         cur = 0;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_build(StepConsts<N> c, co
         }
       }
       flush();
-      nbrCount[i] = written <= NBR_CAP ? written : NBR_OVERFLOW;
+      nbrCount[i] = written <= NBR_ROWS ? written : NBR_OVERFLOW;
     }
   }
 }
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(TILE_THREADS, sizeof(N) == 4 ? 8 : 4) void k_tile_f
       if (!op.begin(c, args, i)) continue;
       const uint32_t cnt = nbrCount[i];
       const uint32_t *mine = nbr_row(nbrList, i);
-      if (cnt == NBR_OVERFLOW) {  // a row longer than NBR_CAP: the whole walk, out of the tile
+      if (cnt == NBR_OVERFLOW) {  // a row longer than NBR_ROWS: the whole walk, out of the tile
         const uint32_t home = tile_home_cell(key[i]);
 #pragma unroll 1
         for (uint32_t r = 0; r < 9; ++r) {
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(TILE_THREADS, sizeof(N) == 4 ? 8 : 4) void k_tile_f
           uint32_t b[4];
           Src cnd[4];
 #pragma unroll
-          for (uint32_t w = 0; w < 4; ++w) b[w] = mine[(q + w) * BLOCK];  // (NBR_CAP is a multiple of 4: in the row)
+          for (uint32_t w = 0; w < 4; ++w) b[w] = mine[(q + w) * BLOCK];  // (NBR_ROWS is a multiple of 4: in the row)
 #pragma unroll
           for (uint32_t w = 0; w < 4; ++w) b[w] = q + w < cnt ? b[w] : 0u;  // a tail slot holds anything: record 0, masked
 #pragma unroll

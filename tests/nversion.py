@@ -109,14 +109,15 @@ def vorticity(ps, vel, h, cells=None):
     return np.cross(vij, -g).sum(1)
 
 
-def vorticity_force_dv(ps, omega, h, dt, cells=None):
+def vorticity_force_dv(ps, omega, h, dt, cells=None, return_eta=False):
     """eq. 16: f = eps (N x omega), N = eta / |eta|, eta = grad |omega|; returns the velocity increment f dt"""
     _, g = pair_tables(ps, h, cells)
     mag = np.sqrt((omega * omega).sum(-1))
     eta = (g * mag[None, :, None]).sum(1)
     ln = np.sqrt((eta * eta).sum(-1))
     nn = np.where((ln > EPSILON)[:, None], eta / np.where(ln > EPSILON, ln, 1.0)[:, None], 0.0)
-    return np.cross(nn, omega) * (VORTICITY_EPSILON * dt)
+    dv = np.cross(nn, omega) * (VORTICITY_EPSILON * dt)
+    return (dv, ln) if return_eta else dv
 
 
 def xsph(ps, vel, h, cells=None):

@@ -221,6 +221,43 @@ def test_pipelined_readers_bit_exact(pkg, oracle, pipeline, fp64):
     assert_state_equal(s.download(), o.get_particles())
 
 
+@pytest.mark.parametrize("split,pipeline,chunks", [(8, 0, 0), (8, 1, 0), (5, 0, 0), (0, 0, 0), (8, 0, 3), (8, 0, 1)])
+def test_two_tier_lists_bit_exact(pkg, oracle, split, pipeline, chunks):
+    """The neighbour lists keep 40 slots per particle in [block][slot][thread] rows and take a 24-slot chunk from a pool for
+    the few longer ones (NbrLists, csrc/pbf_kernels.hpp).  A scene with all three kinds of particle — lists within the rows,
+    lists that spill into a chunk (41..64 survivors), lists beyond 64 (NBR_OVERFLOW: the particle walks) — through every
+    writer (split_build 8 / 5 / 0) and both readers; and with a pool of 3 chunks / 1 chunk, which most spilling particles
+    find empty (they walk instead): identical bits every time."""
+    sc, side = get_scene(pkg, "dam8192", False)
+    sc = {k: v.copy() for k, v in sc.items()}
+    rng = np.random.default_rng(23)
+    sc["pos"][:1500] = sc["pos"][4000] + rng.random((1500, 3)).astype(np.float32) * np.float32(95.0)   # ~1.3x the lattice's density
+    sc["pos"][1500:1800] = sc["pos"][0] + (np.arange(300)[:, None] % 7) * 0.5                         # a pile: > 64 neighbours
+    p, q = params_pair(pkg, oracle, side=side)
+    probe = pkg.Solver(h=0.1)
+    if chunks:
+        probe.set_option("nbr_chunks", chunks)
+    probe.set_option("split_build", split)
+    probe.upload(**sc).stage("predict", p).stage("sort", p).stage("lambda", p)
+    cnt = probe.nbr_counts()
+    spill = ((cnt > 40) & (cnt <= 64)).sum()
+    over = (cnt == 0xFFFFFFFF).sum()
+    if chunks:
+        assert spill <= chunks and over >= 200, (spill, over)     # the pool ran dry: the others walk
+    else:
+        assert spill >= 200 and over >= 100 and (cnt <= 40).sum() >= 4000, (spill, over)
+    s = pkg.Solver(h=0.1)
+    if chunks:
+        s.set_option("nbr_chunks", chunks)
+    s.set_option("split_build", split).set_option("pipeline", pipeline)
+    s.upload(**sc)
+    want = oracle_run(oracle, ("twotier",), sc, False, q, (0, 2))
+    for frame in range(3):
+        s.step(p)
+        if frame in want:
+            assert_state_equal(s.download(), want[frame], f"frame {frame}")
+
+
 def test_no_lds_flag_bit_exact(pkg, oracle):
     """PBF_FLAG_NO_LDS: every gather stage (diffuse included) is the plain one-lane-per-particle walk."""
     sc, side = get_scene(pkg, "dam8192", False)
@@ -658,6 +695,18 @@ def test_ranged_sqrt_and_divide_are_the_ieee_ones(pkg):
     bad = np.zeros(4, np.uint64)
     s._chk(s.L.pbf_selftest_math(s.ctx, bad.ctypes.data_as(C.c_void_p)), "pbf_selftest_math")
     assert bad[0] == 0 and bad[1] == 0 and bad[2] <= 1 and bad[3] == 0, bad
+
+
+def test_fp64_trimmed_sqrt_and_divide_agree_with_the_ieee_ones(pkg):
+    """fp64 pair terms (round 3): sqrt = the compiler's own v_rsq_f64 + Goldschmidt + two-correction sequence without its
+    rescale / class wrappers (identical by construction for x >= 2^-767), divides = Newton from a seed with one
+    exact-residual fma correction.  2^64 operands cannot be swept: 1.07e10 pseudo-random operands per category (4.3e10 in
+    all; every binade of the stated ranges equally often + the pair terms' own ranges densely) against the compiler's
+    IEEE sqrt / divide on the device — not one mismatch allowed."""
+    s = pkg.Solver(h=0.1, fp64=True)
+    bad = np.zeros(4, np.uint64)
+    s._chk(s.L.pbf_selftest_math(s.ctx, bad.ctypes.data_as(C.c_void_p)), "pbf_selftest_math")
+    assert not bad.any(), bad
 
 
 @pytest.mark.parametrize("fp64", [False, True])

@@ -139,11 +139,13 @@ def test_rigid_rotation_vorticity_sign_and_confinement(pkg, fp64):
     ps = ga["pos"].astype(np.float64) / 500.0
     wn = NV.vorticity(ps, ga["vel"].astype(np.float64), 0.1)
     assert np.abs(w - wn).max() <= (1e-10 if fp64 else 2e-4) * np.abs(wn).max()
-    dv = NV.vorticity_force_dv(ps, wn, 0.1, p0.dt)
+    dv, eta = NV.vorticity_force_dv(ps, wn, 0.1, p0.dt, return_eta=True)
     got = gb["vel"].astype(np.float64) - ga["vel"].astype(np.float64)
-    # (N = eta / |eta| is ill-conditioned where the |omega| field is flat — the block's interior: compare where it is not)
-    edge = r > 150.0
-    assert np.abs(got[edge] - dv[edge]).max() <= (1e-8 if fp64 else 5e-3) * np.abs(dv).max()
+    # (N = eta / |eta| is ill-conditioned where the |omega| field is flat, i.e. eta = grad |omega| ~ 0 — the block's
+    # interior and a few symmetric spots of its faces: compare where the direction is well defined)
+    steep = eta > 0.05 * eta.max()
+    assert steep.sum() > 500
+    assert np.abs(got[steep] - dv[steep]).max() <= (1e-8 if fp64 else 5e-3) * np.abs(dv).max()
 
 
 @pytest.mark.parametrize("fp64", [False, True])

@@ -1,13 +1,16 @@
 """Condense the SQ / TCP / TCC counter passes of tools/r02_pmc_sq.sh into one table per kernel with the derived
 figures DESIGN.md quotes: wave-time shares (issue / issue-stall / memory-wait), VALU instructions per wave, lane
 utilisation, the clock the kernel held (SQ_BUSY_CYCLES / 32 shader engines / duration), L1 / L2 requests.
-  python tools/pmc_sq_summary.py <dir with pass*/run_counter_collection.csv> <out.md>"""
+  python tools/pmc_sq_summary.py <dir with pass*/run_counter_collection.csv> <out.md> [limiter.json]
+The optional third argument also writes the machine-readable per-kernel "what binds it" record bench.py quotes in
+roofline.limiter (wave-time shares, VALU pipe share, texture-address busy share when a TA pass is present, clock held)."""
 import glob
 import sys
 
 import pandas as pd
 
 d, out = sys.argv[1], sys.argv[2]
+limiter_out = sys.argv[3] if len(sys.argv) > 3 else None
 rows = []
 for f in sorted(glob.glob(d + "/pass*/run_counter_collection.csv")):
     df = pd.read_csv(f)
@@ -45,3 +48,22 @@ with open(out, "w") as fh:
     fh.write(r.to_markdown())
     fh.write("\n")
 print(r.to_string())
+if limiter_out:
+    import json
+    rec = {}
+    for k, row in r.iterrows():
+        e = {"mean_launch_us": float(row["us"]), "clock_ghz_held": float(row["GHz"]), "clock_ghz_peak": 2.4,
+             "valu_per_wave": float(row["VALU/wave"]), "vmem_per_wave": float(row["VMEM/wave"]), "lds_per_wave": float(row["LDS/wave"]),
+             "lanes_active_frac": float(row["lanes"]), "wave_issue_frac": float(row["issue%"]) / 100,
+             "wave_ready_not_issued_frac": float(row["stall%"]) / 100, "wave_waiting_frac": float(row["wait%"]) / 100,
+             "valu_pipe_busy_frac": float(row["VALUpipe%"]) / 100, "l2_hit_frac": float(row["L2 hit%"]) / 100}
+        if "TA_BUSY_avr" in p.columns and "GRBM_GUI_ACTIVE" in p.columns and p.loc[k, "GRBM_GUI_ACTIVE"] == p.loc[k, "GRBM_GUI_ACTIVE"]:
+            e["texture_address_busy_frac"] = round(float(p.loc[k, "TA_BUSY_avr"] / (p.loc[k, "GRBM_GUI_ACTIVE"] / 8)), 3)
+        # the verdict a reader should take away: which unit is closest to saturation, and that none is saturated
+        shares = {"valu pipe": e["valu_pipe_busy_frac"], "texture-address path": e.get("texture_address_busy_frac", 0.0)}
+        top = max(shares, key=shares.get)
+        e["measured_limiter"] = (f"{top} {shares[top]:.0%} busy, waves waiting {e['wave_waiting_frac']:.0%} / ready-not-issued "
+                                 f"{e['wave_ready_not_issued_frac']:.0%} of their life: "
+                                 + ("no unit saturated - latency / occupancy limited" if shares[top] < 0.7 else f"{top}-bound"))
+        rec[k] = e
+    json.dump(rec, open(limiter_out, "w"), indent=1)
