@@ -259,6 +259,10 @@ int pbf_slab_attach(pbf_ctx *ctx, pbf_comm *comm, const uint32_t *cuts, uint32_t
 int pbf_slab_set_cuts(pbf_ctx *ctx, const uint32_t *cuts); /* load balance: new cuts (same on every rank) */
 int pbf_slab_step(pbf_ctx *ctx, const pbf_params *params);
 int pbf_slab_steps(pbf_ctx *ctx, const pbf_params *params, uint32_t count);
+/* host read-backs pbf_slab_step has made so far: exactly 2 per step — the counts of the two assembly rounds, which size the
+ * append launches and the new particle count (the 2K field rounds need none).  No hipStreamSynchronize: a one-wave kernel
+ * writes the six words and then a sequence number into pinned host memory, the host polls that word. */
+uint64_t pbf_slab_host_syncs(const pbf_ctx *ctx);
 
 /* ---- scene factory (sph.hpp:127-186; dam-break: SURVEY.md §8d) — host only, no GPU needed -- */
 size_t pbf_scene_cubes(int fp64, size_t count, uint64_t *id, uint8_t *type, void *mass, void *pos, void *vel,

@@ -153,6 +153,7 @@ _SIGS = {
     "pbf_slab_set_cuts": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pbf_slab_step": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "pbf_slab_steps": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_uint32]),
+    "pbf_slab_host_syncs": (C.c_uint64, [C.c_void_p]),
     "pbf_scene_cubes": (C.c_size_t, [C.c_int, C.c_size_t] + [C.c_void_p] * 6),
     "pbf_scene_dambreak": (C.c_size_t, [C.c_int, C.c_size_t] + [C.c_void_p] * 6 + [C.POINTER(C.c_double)]),
     "pbf_apply_motion": (None, [C.c_int, C.POINTER(Params), C.c_uint64, C.POINTER(Params)]),

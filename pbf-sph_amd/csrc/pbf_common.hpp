@@ -77,6 +77,17 @@ template <typename N> struct StepConsts {
   uint32_t nWells;
   uint32_t hasObstacles;
   uint32_t xoff;  // slab mode: keys use the x cell coordinate minus xoff (rank-local, compact table); 0 otherwise
+  // pbf_slab_step (round 3): predict itself sorts the particles into stayers / leavers / last step's copies
+  uint32_t slabOn;           // 0: everything below is ignored
+  uint32_t sxlo, sxhi;       // owned cell columns [sxlo, sxhi) in the keys' x frame
+  uint32_t sHasL, sHasR;     // is there a slab on that side
 };
+
+// particle type bits: sph::Type (src/sph.hpp:15) + the slab decomposition's copies
+constexpr uint8_t TYPE_OBSTACLE = 1;
+constexpr uint8_t TYPE_GHOST = 2;  // a copy of a neighbouring slab's boundary particle: a candidate, never updated locally
+// pbf_slab_step: a slot whose particle has left (a migrant that was packed for the neighbour, or last step's copy).  It
+// takes no part in the histogram and the scatter, so the step's sort drops it — no compaction pass of its own.
+constexpr uint32_t DEAD_KEY = 0xFFFFFFFFu;
 
 }  // namespace pbf

@@ -33,7 +33,7 @@ struct DevBuf {
   template <typename T> T *as() const { return static_cast<T *>(p); }
 };
 
-constexpr uint32_t kTickets = 255;
+constexpr uint32_t kTickets = 254;  // (kTickets + 2 words = 1024 bytes: ONE fill kernel per step; 1028 bytes took two)
 constexpr int kBrickZ = 4;
 
 enum Stage { ST_PREDICT = 0, ST_SORT, ST_DIFFUSE, ST_LAMBDA, ST_DELTA, ST_FINALISE, ST_BUILD, ST_COUNT };
@@ -109,6 +109,12 @@ struct pbf_ctx {
   uint32_t capMig = 0, capGhost = 0;  // records in the FIRST message of an assembly round (the rest follows when needed)
   uint32_t wireCap = 0;               // records the wire buffers hold per neighbour
   DevBuf wireSend[2], wireRecv[2];
+  DevBuf wireGhost[2];               // the ghost round's send buffers (packed by the same select pass as the migrants')
+  bool slabStepMode = false;         // inside pbf_slab_step: predict classifies (StepConsts::slabOn)
+  size_t sortLive = 0;               // pbf_slab_step: particles that take part in this step's sort (the others are dead slots)
+  uint32_t ghostAt = 0;              // pre-sort index of the first copy received this step (k_unpack_field)
+  uint32_t slabSeq = 0;              // sequence number of the next read-back (k_slab_counts -> pinned host word)
+  uint64_t slabHostSyncs = 0;        // host read-backs inside pbf_slab_step so far (2 per step: the two assembly rounds)
   uint32_t *hostCounts = nullptr;  // pinned: read-back of the assembly rounds' counts
   size_t reserve = 0;        // pbf_reserve: capacity kept for migrants and ghost copies
   uint32_t nOwned = 0, sentL = 0, sentR = 0, gotL = 0, gotR = 0;
@@ -118,7 +124,7 @@ struct pbf_ctx {
   uint64_t mcTriangles = 0;
   DevBuf qpos;               // 8-byte quantised pStar for the list build (k_build_lists_q)
   DevBuf nbrList, nbrCount;  // neighbour lists handed from the lambda launch to the delta launch: NBR_ROWS slots per particle
-  DevBuf nbrExtra;           // ... + chunks of NBR_EXTRA more slots for the particles that need them (NbrLists)
+  uint64_t nbrExtraAt = 0;   // ... + behind them a pool of NBR_EXTRA-slot chunks for the particles that need more (NbrLists)
   uint32_t nbrChunks = 0, nbrChunksOpt = 0;
   bool nbrValid = false;     // the lists describe pstar[pcur] as it is now
   bool omegaValid = false;   // pstar[2] holds the vorticity of the last extras pass (PBF_BUF_OMEGA), same order as the arrays
@@ -223,6 +229,9 @@ template <typename N> size_t vsz() { return sizeof(vec4<N>); }
 int ensure_particles(pbf_ctx *ctx, size_t n) {
   n = std::max(n, ctx->reserve);
   if (ctx->cap >= n) return PBF_OK;
+  // slab mode (a reserve was asked for): pbf_slab_step leaves the slots of the particles that left — migrants, last step's
+  // copies — in place until the step's sort drops them, so a step transiently needs more slots than live particles
+  if (ctx->reserve) n += n / 4 + 65536;
   const size_t v = ctx->fp64 ? sizeof(double4) : sizeof(float4);
   for (int s = 0; s < 2; ++s) {
     if (int rc = ensure(ctx, ctx->pos4[s], n * v)) return rc;
@@ -239,9 +248,13 @@ int ensure_particles(pbf_ctx *ctx, size_t n) {
   if (int rc = ensure(ctx, ctx->qpos, (n + QPOS_PAD) * 8)) return rc;
   if (int rc = ensure(ctx, ctx->nbrCount, n * 4)) return rc;
   // two-tier lists: NBR_ROWS slots per particle in rows + a pool of NBR_EXTRA-slot chunks for the few longer lists
-  if (int rc = ensure(ctx, ctx->nbrList, ((n + BLOCK - 1) / BLOCK) * size_t(NBR_ROWS) * BLOCK * 4)) return rc;
+  // (one allocation: a lane addresses both tiers from its row pointer with a 32-bit word offset — which caps the whole at
+  // 2^31 words, i.e. ~45 M particles per GPU; beyond that the pool is left out and longer lists walk)
+  const size_t rowWords = ((n + BLOCK - 1) / BLOCK) * size_t(NBR_ROWS) * BLOCK;
   ctx->nbrChunks = ctx->nbrChunksOpt ? ctx->nbrChunksOpt : uint32_t(n / 16 + 1024);  // (option "nbr_chunks": tests shrink the pool)
-  if (int rc = ensure(ctx, ctx->nbrExtra, size_t(ctx->nbrChunks) * NBR_EXTRA * 4)) return rc;
+  if (rowWords + size_t(ctx->nbrChunks) * NBR_EXTRA >= (size_t(1) << 31)) ctx->nbrChunks = 0;
+  ctx->nbrExtraAt = rowWords;
+  if (int rc = ensure(ctx, ctx->nbrList, (rowWords + size_t(ctx->nbrChunks) * NBR_EXTRA + 64) * 4)) return rc;
   ctx->cap = n;
   return PBF_OK;
 }
@@ -286,6 +299,14 @@ template <typename N> int make_consts(pbf_ctx *ctx, const pbf_params *p, StepCon
     ctx->extent[i] = ext[i];
   }
   c.xoff = 0;
+  c.slabOn = 0, c.sxlo = 0, c.sxhi = 0xFFFFFFFFu, c.sHasL = c.sHasR = 0;
+  if (ctx->slabStepMode && ctx->comm) {  // pbf_slab_step: predict sorts the particles into stayers / leavers / old copies
+    const uint32_t xo = ctx->slabConfigured ? ctx->xoff : 0u;
+    const int r = ctx->comm->rank, nr = ctx->comm->nranks;
+    c.slabOn = 1;
+    c.sxlo = ctx->cuts[r] - std::min(ctx->cuts[r], xo), c.sxhi = ctx->cuts[r + 1] - std::min(ctx->cuts[r + 1], xo);
+    c.sHasL = r > 0 ? 1u : 0u, c.sHasR = r + 1 < nr ? 1u : 0u;
+  }
   if (ctx->slabConfigured) {  // keys live in this rank's x frame: columns [xoff, right ghost column]
     c.xoff = ctx->xoff;
     const uint64_t hi = ctx->slabCut.has_right ? std::min<uint64_t>(ext[0], uint64_t(ctx->slabCut.xhi) + 1) : ext[0];
@@ -459,9 +480,13 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
   hipLaunchKernelGGL(k_sort_big_cells, dim3(64), dim3(BLOCK), 0, ctx->stream, table, c.tableN,
                      ctx->bigCells.as<const uint32_t>(), nBig, ctx->permTmp.as<uint32_t>(),
                      ctx->key[s].as<const uint32_t>());
-  hipLaunchKernelGGL((k_rank_move<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, c.n, c.tableN,
+  // pbf_slab_step: the arrays still hold the slots of the particles that left (DEAD_KEY: skipped by the scatter); only
+  // the live ones arrive in the sorted set
+  const size_t nLive = ctx->slabStepMode ? ctx->sortLive : ctx->n;
+  hipLaunchKernelGGL((k_rank_move<N>), grid_for(nLive), dim3(BLOCK), 0, ctx->stream, c, uint32_t(nLive), c.tableN,
                      ctx->permTmp.as<const uint32_t>(), table, arrays<N>(ctx, s, s), arrays<N>(ctx, d, d),
                      ctx->slabActive ? ctx->slotOf.as<uint32_t>() : nullptr, ctx->qpos.as<uint2>());
+  ctx->n = nLive;
   {  // list of non-empty bricks for the persistent gather kernels (+ fresh tickets)
     const uint32_t home = Brick<kBrickZ>::HOME, nBricks = (c.tableN + home - 1) / home;
     hipLaunchKernelGGL(k_brick_list, grid_for(nBricks), dim3(BLOCK), 0, ctx->stream, table, c.tableN, home, nBricks,
@@ -497,8 +522,8 @@ uint32_t *next_ticket(pbf_ctx *ctx) {
 }
 // build = this launch WRITES the lists (takes a fresh chunk allocator)
 NbrLists nbr_lists(pbf_ctx *ctx, bool build) {
-  return NbrLists{ctx->nbrList.as<uint32_t>(), ctx->nbrCount.as<uint32_t>(), ctx->nbrExtra.as<uint32_t>(),
-                  build ? next_ticket(ctx) : nullptr, ctx->nbrChunks};
+  return NbrLists{ctx->nbrList.as<uint32_t>(), ctx->nbrCount.as<uint32_t>(), build ? next_ticket(ctx) : nullptr,
+                  ctx->nbrExtraAt, ctx->nbrChunks};
 }
 
 template <typename N, typename Op>
@@ -1039,7 +1064,7 @@ void pbf_destroy(pbf_ctx *ctx) {
                    &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2], &ctx->count, &ctx->table,   &ctx->blockSums,
                    &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl, &ctx->bigCells,
                    &ctx->latticePN, &ctx->latticeC, &ctx->mcCounts, &ctx->mcOffsets, &ctx->mcSums, &ctx->meshV, &ctx->meshN,
-                   &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->nbrExtra, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR, &ctx->colHist, &ctx->wireSend[0], &ctx->wireSend[1], &ctx->wireRecv[0], &ctx->wireRecv[1], &ctx->diffSum, &ctx->diffCnt};
+                   &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR, &ctx->colHist, &ctx->wireSend[0], &ctx->wireSend[1], &ctx->wireRecv[0], &ctx->wireRecv[1], &ctx->wireGhost[0], &ctx->wireGhost[1], &ctx->diffSum, &ctx->diffCnt};
   for (DevBuf *b : all)
     if (b->p) (void)hipFree(b->p);
   for (auto &g : ctx->graphs)
@@ -1512,6 +1537,7 @@ template <typename N> int slab_add_ghosts(pbf_ctx *ctx, const void *rL, uint32_t
                        static_cast<const GhostRec<N> *>(rL), nL, static_cast<const GhostRec<N> *>(rR), nR,
                        ctx->shiftL, ctx->shiftR, arrays<N>(ctx, ctx->cur, ctx->pcur));
   ctx->gotL = nL, ctx->gotR = nR;
+  ctx->ghostAt = uint32_t(ctx->n);
   ctx->n += nL + nR;
   if (nL + nR) ctx->hasObstacles = true;  // "special" particles exist: the kernels must look at type[]
   // histogram of the re-assembled set (owned + copies) for the sort
@@ -1543,7 +1569,7 @@ template <typename N> int slab_unpack(pbf_ctx *ctx, const void *rL, const void *
   if (!ctx->haveParams) return fail(ctx, PBF_ERR_STATE, "pbf_slab_unpack before any stage");
   if (int rc = make_consts<N>(ctx, &ctx->lastParams, c)) return rc;
   if (m)
-    hipLaunchKernelGGL((k_unpack_field<N>), grid_for(m), dim3(BLOCK), 0, ctx->stream, c, ctx->nOwned, ctx->gotL, ctx->gotR,
+    hipLaunchKernelGGL((k_unpack_field<N>), grid_for(m), dim3(BLOCK), 0, ctx->stream, c, ctx->ghostAt, ctx->gotL, ctx->gotR,
                        static_cast<const vec4<N> *>(rL), static_cast<const vec4<N> *>(rR),
                        ctx->slotOf.as<const uint32_t>(), field ? static_cast<vec4<N> *>(field) : ctx->pstar[ctx->pcur].as<vec4<N>>(),
                        field ? nullptr : ctx->qpos.as<uint2>());
@@ -1712,42 +1738,6 @@ int exchange(pbf_ctx *ctx, size_t nSL, size_t nSR, size_t nRL, size_t nRR, size_
   return rc;
 }
 
-// One assembly round: select + pack (MODE), counts into the message headers, ONE exchange of a fixed-size first
-// message {header | first `chunk` records}, then one small read-back {own totals[3], header from the left, header
-// from the right}.  Only when a side holds more than `chunk` records (a re-cut hands whole columns over; the start
-// lattice's blow-up) a second exchange moves the remainder — with exact sizes, which both ends of a link know by then.
-template <typename N, int MODE>
-int assembly_round(pbf_ctx *ctx, uint32_t chunk, size_t recBytes, int idxL, int idxR, uint32_t own[3], uint32_t got[2]) {
-  const pbf_slab_cut cut = cut_of(ctx);
-  uint8_t *sL = ctx->wireSend[0].as<uint8_t>(), *sR = ctx->wireSend[1].as<uint8_t>();
-  uint8_t *rL = ctx->wireRecv[0].as<uint8_t>(), *rR = ctx->wireRecv[1].as<uint8_t>();
-  uint32_t t[3];
-  if (int rc = ensure(ctx, ctx->selTotals, 16)) return rc;
-  if (ctx->n == 0) HIPCHK(ctx, hipMemsetAsync(ctx->selTotals.p, 0, 16, ctx->stream));
-  if (int rc = run_select<N, MODE>(ctx, &cut, sL + WIRE_HDR, sR + WIRE_HDR, ctx->wireCap, t, false)) return rc;
-  hipLaunchKernelGGL(k_wire_headers, dim3(1), dim3(64), 0, ctx->stream, ctx->selTotals.as<const uint32_t>(), idxL, idxR,
-                     reinterpret_cast<uint32_t *>(sL), reinterpret_cast<uint32_t *>(sR), reinterpret_cast<uint32_t *>(rL),
-                     reinterpret_cast<uint32_t *>(rR));
-  LAUNCH_CHECK(ctx);
-  const size_t first = WIRE_HDR + size_t(chunk) * recBytes;
-  if (int rc = exchange(ctx, first, first, first, first)) return rc;
-  uint32_t *h = ctx->hostCounts;  // pinned, device-visible: the kernel writes the six words itself
-  hipLaunchKernelGGL(k_wire_counts, dim3(1), dim3(64), 0, ctx->stream, ctx->selTotals.as<const uint32_t>(),
-                     reinterpret_cast<const uint32_t *>(rL), reinterpret_cast<const uint32_t *>(rR), h);
-  LAUNCH_CHECK(ctx);
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the one read-back of this round: counts size the launches below
-  own[0] = h[0], own[1] = h[1], own[2] = h[2];
-  got[0] = h[4], got[1] = h[5];
-  const uint32_t most = std::max(std::max(own[idxL], own[idxR]), std::max(got[0], got[1]));
-  if (most > ctx->wireCap)
-    return fail(ctx, PBF_ERR_COMM, "slab wire buffers too small (" + std::to_string(most) + " records > " +
-                                       std::to_string(ctx->wireCap) + "): pbf_reserve a larger particle capacity before attaching");
-  auto rest = [&](uint32_t count) { return count > chunk ? size_t(count - chunk) * recBytes : size_t(0); };
-  if (most > chunk)  // (both ends of a link see the same count for it: sizes agree, empty links are skipped)
-    if (int rc = exchange(ctx, rest(own[idxL]), rest(own[idxR]), rest(got[0]), rest(got[1]), first)) return rc;
-  return PBF_OK;
-}
-
 // The opt-in extras in slab mode: the same three gather ops as extras_impl, with the owners refreshing their copies'
 // velocity / vorticity before each op that reads them (the copies' velocities are not part of the ghost records).
 template <typename N, bool FAST> int slab_extras_impl(pbf_ctx *ctx, const pbf_params *p) {
@@ -1783,20 +1773,140 @@ template <typename N, bool FAST> int slab_extras_impl(pbf_ctx *ctx, const pbf_pa
   return PBF_OK;
 }
 
+// Spin on the pinned word k_slab_counts writes last.  A kernel fault or a lost device would leave it unwritten for ever:
+// every ~2 ms of spinning the stream is queried, and an error (or an idle stream without the word) ends the wait.
+int wait_for_counts(pbf_ctx *ctx, uint32_t seq) {
+  volatile uint32_t *h = ctx->hostCounts;
+  for (uint64_t spin = 1;; ++spin) {
+    if (h[7] == seq) return PBF_OK;
+    if ((spin & 0xFFFFu) == 0) {
+      const hipError_t e = hipStreamQuery(ctx->stream);
+      if (e == hipSuccess) {
+        if (h[7] == seq) return PBF_OK;
+        return fail(ctx, PBF_ERR_HIP, "slab read-back: the stream went idle without delivering the counts");
+      }
+      if (e != hipErrorNotReady) {
+        ctx->err = std::string("slab read-back: ") + hipGetErrorString(e);
+        return PBF_ERR_HIP;
+      }
+    }
+  }
+}
+
+// One step of the slab protocol, everything on the solver's stream (round 3: ONE select pass, no compaction, no
+// re-histogram, finalise + predict fused between the steps of one pbf_slab_steps call):
+//   predict (classifies: stayers into the histogram, leavers and last step's copies not)
+//   select: leavers -> migrant wire (their slots die), copies of the boundary stayers -> ghost wire       [3 small kernels]
+//   [migrants]  exchange, read-back #1 (how many arrived), append + histogram, copies of boundary arrivals -> ghost wire
+//   [copies]    exchange, read-back #2 (how many copies each way), append + histogram
+//   sort (skips the dead slots: this is where the leavers and the old copies disappear) -> diffuse -> K x { lambda ->
+//   [field] -> delta -> [field] } -> finalise (+ next predict)
 template <typename N> int slab_step_impl(pbf_ctx *ctx, const pbf_params *p) {
-  if (int rc = stage_predict<N>(ctx, p)) return rc;
-  const uint8_t *rL = ctx->wireRecv[0].as<const uint8_t>() + WIRE_HDR, *rR = ctx->wireRecv[1].as<const uint8_t>() + WIRE_HDR;
-  uint32_t own[3], got[2];
-  // ---- round 1: particles whose cell column left the slab move to the neighbour --------------------------
-  if (int rc = drop_histogram(ctx)) return rc;  // predict's histogram describes the pre-migration set
-  if (int rc = assembly_round<N, SEL_MIGRATE>(ctx, ctx->capMig, sizeof(MigrantRec<N>), 1, 2, own, got)) return rc;
-  if (ctx->n) ctx->cur = 1 - ctx->cur, ctx->pcur = ctx->cur;  // the keeps were compacted into the other array set
-  ctx->n = own[0], ctx->nOwned = own[0], ctx->sorted = false;
-  if (int rc = slab_add_migrants<N>(ctx, rL, got[0], rR, got[1])) return rc;
-  // ---- round 2: copies of the boundary columns ------------------------------------------------------------
-  if (int rc = assembly_round<N, SEL_GHOST>(ctx, ctx->capGhost, sizeof(GhostRec<N>), 0, 1, own, got)) return rc;
-  ctx->sentL = own[0], ctx->sentR = own[1];
-  if (int rc = slab_add_ghosts<N>(ctx, rL, got[0], rR, got[1])) return rc;
+  struct ModeGuard {
+    pbf_ctx *c;
+    ~ModeGuard() { c->slabStepMode = false; }
+  } guard{ctx};
+  ctx->slabStepMode = true;
+  if (ctx->prePredicted) {
+    ctx->prePredicted = false;  // the previous step of this pbf_slab_steps call has predicted already (k_finalise_predict)
+  } else if (int rc = stage_predict<N>(ctx, p)) {
+    return rc;
+  }
+  StepConsts<N> c;
+  if (int rc = make_consts<N>(ctx, p, c)) return rc;
+  const uint32_t nPrev = uint32_t(ctx->n), oldCopies = ctx->ghostsPending ? ctx->gotL + ctx->gotR : 0u;
+  const pbf_slab_cut cut = cut_of(ctx);
+  const SlabCut sc{c.sxlo, c.sxhi, c.sHasL, c.sHasR};
+  (void)cut;
+  uint8_t *mL = ctx->wireSend[0].as<uint8_t>(), *mR = ctx->wireSend[1].as<uint8_t>();
+  uint8_t *gL = ctx->wireGhost[0].as<uint8_t>(), *gR = ctx->wireGhost[1].as<uint8_t>();
+  uint8_t *rL = ctx->wireRecv[0].as<uint8_t>(), *rR = ctx->wireRecv[1].as<uint8_t>();
+  const int a = ctx->cur;
+  const uint32_t nb = std::max(1u, (nPrev + SEL_TILE - 1) / SEL_TILE);
+  if (int rc = ensure(ctx, ctx->selCounts, size_t(4) * nb * 4)) return rc;
+  if (int rc = ensure(ctx, ctx->selTotals, 16)) return rc;
+  if (int rc = ensure(ctx, ctx->ghostSrcL, size_t(ctx->wireCap) * 4)) return rc;
+  if (int rc = ensure(ctx, ctx->ghostSrcR, size_t(ctx->wireCap) * 4)) return rc;
+  uint32_t *counts = ctx->selCounts.as<uint32_t>(), *tot = ctx->selTotals.as<uint32_t>();
+  volatile uint32_t *h = ctx->hostCounts;
+  // ---- the select: one pass for both rounds --------------------------------------------------------------------
+  hipLaunchKernelGGL(k_slab_count, dim3(nb), dim3(BLOCK), 0, ctx->stream, nPrev, sc, ctx->key[a].as<const uint32_t>(),
+                     ctx->type[a].as<const uint8_t>(), nb, counts);
+  hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(BLOCK), 0, ctx->stream, nb, counts, tot, reinterpret_cast<uint32_t *>(mL),
+                     reinterpret_cast<uint32_t *>(mR), reinterpret_cast<uint32_t *>(gL), reinterpret_cast<uint32_t *>(gR),
+                     reinterpret_cast<uint32_t *>(rL), reinterpret_cast<uint32_t *>(rR));
+  hipLaunchKernelGGL((k_slab_emit<N>), dim3(nb), dim3(BLOCK), 0, ctx->stream, nPrev, sc, arrays<N>(ctx, a, ctx->pcur), nb, counts,
+                     reinterpret_cast<MigrantRec<N> *>(mL + WIRE_HDR), reinterpret_cast<MigrantRec<N> *>(mR + WIRE_HDR),
+                     reinterpret_cast<GhostRec<N> *>(gL + WIRE_HDR), reinterpret_cast<GhostRec<N> *>(gR + WIRE_HDR), ctx->wireCap,
+                     ctx->ghostSrcL.as<uint32_t>(), ctx->ghostSrcR.as<uint32_t>());
+  LAUNCH_CHECK(ctx);
+  // an exchange round: fixed-size first message {header | first `chunk` records}; the rest, when a side holds more
+  // (a re-cut hands whole columns over), in a second, exactly sized exchange once both ends know the counts
+  auto round = [&](uint8_t *sL, uint8_t *sR, uint32_t chunk, size_t recBytes, int idxL, int idxR, uint32_t got[2]) -> int {
+    const size_t first = WIRE_HDR + size_t(chunk) * recBytes;
+    if (int rc = comm_exchange(ctx->comm, ctx->stream, sL, first, sR, first, rL, first, rR, first)) {
+      ctx->err = "slab exchange: " + ctx->comm->err;
+      return rc;
+    }
+    const uint32_t seq = ++ctx->slabSeq;
+    hipLaunchKernelGGL(k_slab_counts, dim3(1), dim3(64), 0, ctx->stream, tot, reinterpret_cast<uint32_t *>(rL),
+                       reinterpret_cast<uint32_t *>(rR), h, seq);
+    LAUNCH_CHECK(ctx);
+    // the one read-back of this round (the counts size the launches below): the host POLLS the pinned sequence word the
+    // kernel writes last — a few microseconds after the kernel retires, where hipStreamSynchronize took 15-30
+    if (int rc = wait_for_counts(ctx, seq)) return rc;
+    ctx->slabHostSyncs++;
+    got[0] = h[4], got[1] = h[5];
+    const uint32_t ownL = h[idxL], ownR = h[idxR];
+    const uint32_t most = std::max(std::max(ownL, ownR), std::max(got[0], got[1]));
+    if (most > ctx->wireCap)
+      return fail(ctx, PBF_ERR_COMM, "slab wire buffers too small (" + std::to_string(most) + " records > " +
+                                         std::to_string(ctx->wireCap) + "): pbf_reserve a larger particle capacity before attaching");
+    auto rest = [&](uint32_t count) { return count > chunk ? size_t(count - chunk) * recBytes : size_t(0); };
+    if (most > chunk)
+      if (int rc = comm_exchange(ctx->comm, ctx->stream, sL + first, rest(ownL), sR + first, rest(ownR), rL + first,
+                                 rest(got[0]), rR + first, rest(got[1]))) {
+        ctx->err = "slab exchange: " + ctx->comm->err;
+        return rc;
+      }
+    return PBF_OK;
+  };
+  // ---- round 1: particles whose cell column left the slab move to the neighbour -------------------------------
+  uint32_t got[2];
+  if (int rc = round(mL, mR, ctx->capMig, sizeof(MigrantRec<N>), 0, 1, got)) return rc;
+  const uint32_t leavers = h[0] + h[1], arrived = got[0] + got[1];
+  if (size_t(nPrev) + arrived > ctx->cap) return fail(ctx, PBF_ERR_INVALID, "particle capacity exceeded: call pbf_reserve");
+  if (arrived) {
+    hipLaunchKernelGGL((k_append_migrants_h<N>), grid_for(arrived), dim3(BLOCK), 0, ctx->stream, nPrev,
+                       reinterpret_cast<const MigrantRec<N> *>(rL + WIRE_HDR), got[0],
+                       reinterpret_cast<const MigrantRec<N> *>(rR + WIRE_HDR), got[1], ctx->shiftL, ctx->shiftR,
+                       arrays<N>(ctx, a, ctx->pcur), c.tableN, ctx->count.as<uint32_t>());
+    hipLaunchKernelGGL((k_slab_arrival_ghosts<N>), dim3(1), dim3(BLOCK), 0, ctx->stream, nPrev, arrived, sc,
+                       arrays<N>(ctx, a, ctx->pcur), tot, reinterpret_cast<GhostRec<N> *>(gL + WIRE_HDR),
+                       reinterpret_cast<GhostRec<N> *>(gR + WIRE_HDR), reinterpret_cast<uint32_t *>(gL),
+                       reinterpret_cast<uint32_t *>(gR), ctx->wireCap, ctx->ghostSrcL.as<uint32_t>(), ctx->ghostSrcR.as<uint32_t>());
+    LAUNCH_CHECK(ctx);
+  }
+  // ---- round 2: copies of the boundary columns -------------------------------------------------------------------
+  if (int rc = round(gL, gR, ctx->capGhost, sizeof(GhostRec<N>), 2, 3, got)) return rc;
+  ctx->sentL = h[2], ctx->sentR = h[3];
+  const uint32_t copies = got[0] + got[1];
+  if (size_t(nPrev) + arrived + copies > ctx->cap) return fail(ctx, PBF_ERR_INVALID, "particle capacity exceeded: call pbf_reserve");
+  ctx->ghostAt = nPrev + arrived;
+  if (copies) {
+    hipLaunchKernelGGL((k_append_ghosts_h<N>), grid_for(copies), dim3(BLOCK), 0, ctx->stream, ctx->ghostAt,
+                       reinterpret_cast<const GhostRec<N> *>(rL + WIRE_HDR), got[0],
+                       reinterpret_cast<const GhostRec<N> *>(rR + WIRE_HDR), got[1], ctx->shiftL, ctx->shiftR,
+                       arrays<N>(ctx, a, ctx->pcur), c.tableN, ctx->count.as<uint32_t>());
+    LAUNCH_CHECK(ctx);
+    ctx->hasObstacles = true;  // "special" particles exist: the kernels must look at type[]
+  }
+  ctx->gotL = got[0], ctx->gotR = got[1];
+  ctx->n = size_t(nPrev) + arrived + copies;                      // slots, dead ones included
+  ctx->sortLive = ctx->n - oldCopies - leavers;                   // what the sort keeps
+  ctx->nOwned = uint32_t(ctx->sortLive - copies);
+  ctx->slabActive = true;
+  ctx->counted = true, ctx->countedTableN = c.tableN;
   if (int rc = stage_sort<N>(ctx, p)) return rc;
   if (int rc = stage_diffuse<N>(ctx, p, /*overlap=*/p->iteration > 0)) return rc;  // beside the iterations, like pbf_step
   // ---- K x { lambda, delta-p }, each followed by the owners refreshing their copies' {pStar, lambda} ------
@@ -1816,8 +1926,8 @@ template <typename N> int slab_step_impl(pbf_ctx *ctx, const pbf_params *p) {
   if (p->vorticity || p->xsph)
     if (int rc = ctx->fast ? slab_extras_impl<N, true>(ctx, p) : slab_extras_impl<N, false>(ctx, p)) return rc;
   if (int rc = join_diffuse(ctx)) return rc;
-  // The copies stay where they are: the next step's migration select drops them on its way (one whole-array
-  // compaction per step saved); whoever looks at the arrays from outside calls drop_ghosts() first.
+  // The copies stay where they are: the next step's predict marks them dead and its sort drops them; whoever looks at
+  // the arrays from outside calls drop_ghosts() first.
   ctx->ghostsPending = true;
   return PBF_OK;
 }
@@ -1930,8 +2040,12 @@ int pbf_slab_attach(pbf_ctx *ctx, pbf_comm *comm, const uint32_t *cuts, uint32_t
   for (int k = 0; k < 2; ++k) {
     if (int rc = ensure(ctx, ctx->wireSend[k], bytes)) return rc;
     if (int rc = ensure(ctx, ctx->wireRecv[k], bytes)) return rc;
+    if (int rc = ensure(ctx, ctx->wireGhost[k], bytes)) return rc;
   }
-  if (!ctx->hostCounts) HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->hostCounts), 64, hipHostMallocDefault));
+  if (!ctx->hostCounts) {
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->hostCounts), 64, hipHostMallocDefault));
+    std::memset(ctx->hostCounts, 0, 64);
+  }
   return pbf_slab_set_cuts(ctx, cuts);
 }
 
@@ -1939,10 +2053,22 @@ int pbf_slab_step(pbf_ctx *ctx, const pbf_params *p) { return pbf_slab_steps(ctx
 int pbf_slab_steps(pbf_ctx *ctx, const pbf_params *p, uint32_t count) {
   if (int rc = check(ctx, p, false)) return rc;
   if (!ctx->comm) return fail(ctx, PBF_ERR_STATE, "pbf_slab_step needs pbf_slab_attach first");
-  for (uint32_t i = 0; i < count; ++i)
-    if (int rc = DISPATCH(ctx, slab_step_impl, ctx, p)) return rc;
+  // finalise(t) + predict(t + 1) as one kernel between two steps of THIS call (same parameters, same cuts, nothing looks
+  // at the state in between) — like pbf_steps
+  const bool timed = (ctx->desc.flags & PBF_FLAG_STAGE_TIMING) != 0 &&
+                     (((ctx->timingMask >> ST_PREDICT) & 1u) != 0 || ((ctx->timingMask >> ST_FINALISE) & 1u) != 0);
+  const bool fusable = ctx->fusePredict && !timed && !(p->vorticity || p->xsph);
+  for (uint32_t i = 0; i < count; ++i) {
+    ctx->fuseNextPredict = fusable && i + 1 < count;
+    if (int rc = DISPATCH(ctx, slab_step_impl, ctx, p)) {
+      ctx->fuseNextPredict = ctx->prePredicted = false;
+      return rc;
+    }
+  }
+  ctx->fuseNextPredict = false;
   return PBF_OK;
 }
+uint64_t pbf_slab_host_syncs(const pbf_ctx *ctx) { return ctx ? ctx->slabHostSyncs : 0; }
 
 }  // extern "C"
 

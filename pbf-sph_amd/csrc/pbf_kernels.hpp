@@ -86,6 +86,14 @@ __device__ inline vec4<N> predict_one(const StepConsts<N> &c, const vec4<N> &p, 
   return make_vec4<N>(px, py, pz, N(0));
 }
 
+// pbf_slab_step: does a particle with this key still belong to this slab (its cell column inside [sxlo, sxhi), or no slab
+// on the side it left to)?  Always true outside slab mode.
+template <typename N> __device__ inline bool slab_stays(const StepConsts<N> &c, uint32_t key) {
+  if (!c.slabOn) return true;
+  const uint32_t cx = compact10(key);
+  return !((c.sHasL && cx < c.sxlo) || (c.sHasR && cx >= c.sxhi));
+}
+
 template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_predict(StepConsts<N> c, const vec4<N> *__restrict__ pos4,
                                                    vec4<N> *__restrict__ vel4, const uint8_t *__restrict__ type,
@@ -93,13 +101,18 @@ __global__ __launch_bounds__(BLOCK) void k_predict(StepConsts<N> c, const vec4<N
                                                    uint32_t *__restrict__ key, uint32_t *__restrict__ count) {
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= c.n) return;
+  const uint8_t ty = c.hasObstacles ? type[i] : uint8_t(0);
+  if (c.slabOn && (ty & TYPE_GHOST)) {  // last step's copy of a neighbour's particle: gone (the sort drops the slot)
+    key[i] = DEAD_KEY;
+    return;
+  }
   const vec4<N> p = pos4[i];
   vec4<N> v = vel4[i];
-  const uint8_t ty = c.hasObstacles ? type[i] : uint8_t(0);
   uint32_t k;
   pstar[i] = predict_one<N>(c, p, v, ty, wells, k);
   if (!(c.hasObstacles && (ty & 1))) vel4[i] = v;
   key[i] = k;
+  if (!slab_stays(c, k)) return;  // its column now belongs to a neighbour: packed and dropped by the slab select
   // bucket tableN collects particles outside the table: they are "in no cell" (sph.hpp:206)
   uint32_t before, rank;
   wave_bucket_atomic(min(k, c.tableN), [&](uint32_t b, uint32_t cnt) { return atomicAdd(&count[b], cnt); }, before, rank);
@@ -248,7 +261,9 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_slots(uint32_t n, uint32_t ta
                                                          uint32_t *__restrict__ nBig) {
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
-  const uint32_t b = min(key[i], tableN);
+  const uint32_t k = key[i];
+  if (k == DEAD_KEY) return;  // pbf_slab_step: a slot whose particle has left takes no place in the sorted array
+  const uint32_t b = min(k, tableN);
   uint32_t before, rank;
   wave_bucket_atomic(b, [&](uint32_t bb, uint32_t cnt) { return atomicSub(&count[bb], cnt); }, before, rank);
   const uint32_t r = before - 1u - rank;  // r runs m - 1 .. 0 over the cell's m members (which member gets which: arbitrary)
@@ -1132,28 +1147,37 @@ constexpr uint32_t NBR_OVERFLOW = 0xFFFFFFFFu;
 constexpr uint32_t NBR_NO_CHUNK = 0xFFFFFFFFu;
 static_assert(NBR_ROWS % 4 == 0 && NBR_EXTRA % 4 == 0 && NBR_CAP < 256, "readers take 4 entries per trip; the length lives in 8 bits");
 struct NbrLists {
-  uint32_t *rows;    // [block][NBR_ROWS][BLOCK]
+  uint32_t *rows;    // [block][NBR_ROWS][BLOCK], and behind them, in the SAME allocation (so that a lane addresses both
+                     // tiers with one base and a 32-bit offset), the pool: [chunk][NBR_EXTRA] from word `extraAt` on
   uint32_t *count;   // per particle: length | chunk << 8 (chunk only meaningful when length > NBR_ROWS), or NBR_OVERFLOW
-  uint32_t *extra;   // [chunk][NBR_EXTRA]
   uint32_t *ticket;  // this launch's chunk allocator: a word that is zero when the launch starts
+  uint64_t extraAt;  // first word of the pool
   uint32_t chunks;   // chunks in the pool
 };
-// one particle's list as its lane writes it, slot by slot in walk order
+// One particle's list as its lane writes it, slot by slot in walk order.  The hot loops of the list builds store a staged
+// batch at a time: reserve(first, count) BEFORE the batch takes the chunk when the batch reaches beyond the rows (one
+// test per batch, an atomic for the few lanes that need one), put() is then a branch-free predicated store.
 struct NbrWriter {
-  uint32_t *row;     // this lane's column of its block's rows
+  uint32_t *row;          // this lane's column of its block's rows
+  int32_t extraDelta = 0;  // word offset from `row` to this lane's chunk (valid once chunk != NBR_NO_CHUNK and in the pool)
   uint32_t chunk = NBR_NO_CHUNK;
+  bool pooled = false;
   __device__ NbrWriter(const NbrLists &l, uint32_t block, uint32_t tid) : row(l.rows + size_t(block) * NBR_ROWS * BLOCK + tid) {}
-  __device__ void put(const NbrLists &l, uint32_t slot, uint32_t b) {
-    if (slot < NBR_ROWS) {
-      row[slot * BLOCK] = b;
-    } else if (slot < NBR_CAP) {
-      if (chunk == NBR_NO_CHUNK) chunk = atomicAdd(l.ticket, 1u);
-      if (chunk < l.chunks) l.extra[size_t(chunk) * NBR_EXTRA + (slot - NBR_ROWS)] = b;
+  __device__ void reserve(const NbrLists &l, uint32_t first, uint32_t count) {
+    if (first + count > NBR_ROWS && count != 0u && chunk == NBR_NO_CHUNK) {
+      chunk = atomicAdd(l.ticket, 1u);
+      pooled = chunk < l.chunks;
+      extraDelta = int32_t(int64_t(l.extraAt + uint64_t(chunk) * NBR_EXTRA) - int64_t(row - l.rows)) - int32_t(NBR_ROWS);
     }
   }
-  __device__ uint32_t finish(const NbrLists &l, uint32_t written) const {
+  __device__ void put(uint32_t slot, uint32_t b, bool valid) const {
+    const bool inRows = slot < NBR_ROWS;
+    const int32_t at = inRows ? int32_t(slot * BLOCK) : extraDelta + int32_t(slot);
+    if (valid && (inRows || (pooled && slot < NBR_CAP))) row[at] = b;
+  }
+  __device__ uint32_t finish(uint32_t written) const {
     if (written <= NBR_ROWS) return written;
-    return (written <= NBR_CAP && chunk < l.chunks) ? (written | (chunk << 8)) : NBR_OVERFLOW;
+    return (written <= NBR_CAP && pooled) ? (written | (chunk << 8)) : NBR_OVERFLOW;
   }
 };
 // ... and as a reader sees it
@@ -1164,7 +1188,7 @@ struct NbrReader {
     const uint32_t raw = l.count[i];
     row = l.rows + size_t(i / BLOCK) * NBR_ROWS * BLOCK + (i % BLOCK);
     cnt = raw == NBR_OVERFLOW ? raw : (raw & 0xFFu);
-    extra = l.extra + size_t(raw == NBR_OVERFLOW || (raw & 0xFFu) <= NBR_ROWS ? 0u : raw >> 8) * NBR_EXTRA;
+    extra = l.rows + l.extraAt + size_t(raw == NBR_OVERFLOW || (raw & 0xFFu) <= NBR_ROWS ? 0u : raw >> 8) * NBR_EXTRA;
   }
   // any slot (the pipelined / cooperative readers); slots past the list are clamped into it and their entries discarded
   __device__ uint32_t entry(uint32_t slot) const {
@@ -1206,11 +1230,12 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
   uint32_t nl = 0, written = 0;
   NbrWriter wr(lists, chunk, tid);
   auto drain = [&]() {
+    if (SAVE) wr.reserve(lists, written, nl);
 #pragma unroll 2
     for (uint32_t q = 0; __any(q < nl); ++q) {
       const bool valid = q < nl;
       const uint32_t b = valid ? list[q * BLOCK + tid] : i;
-      if (SAVE && valid) wr.put(lists, written + q, b);
+      if (SAVE) wr.put(written + q, b, valid);
       op.add_bf(c, Op::load(args, b), valid);
     }
     written += nl;
@@ -1261,7 +1286,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_lists(StepConsts<N> c, typenam
       }
     }
   drain();
-  if (SAVE) lists.count[i] = wr.finish(lists, written);
+  if (SAVE) lists.count[i] = wr.finish(written);
   op.end(c, args, i);
   if constexpr (FUSED) extra.end(c, xargs, i);
 }
@@ -1340,8 +1365,8 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const 
   NbrWriter wr(lists, chunk, tid);
   uint32_t written = 0, nl = 0;
   auto flush = [&]() {
-    for (uint32_t q = 0; __any(q < nl); ++q)
-      if (q < nl) wr.put(lists, written + q, list[q * BLOCK + tid]);
+    wr.reserve(lists, written, nl);
+    for (uint32_t q = 0; __any(q < nl); ++q) wr.put(written + q, list[q * BLOCK + tid], q < nl);
     written += nl;
     nl = 0;
   };
@@ -1403,7 +1428,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_q(StepConsts<N> c, const 
     }
   }
   flush();
-  lists.count[i] = wr.finish(lists, written);
+  lists.count[i] = wr.finish(written);
 }
 
 // The same build with an op riding on it (option split_build = 8): the survivors staged in LDS are not only flushed to
@@ -1441,6 +1466,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_op(StepConsts<N> c, typen
   NbrWriter wr(lists, chunk, tid);
   uint32_t written = 0, nl = 0;
   auto flush = [&]() {
+    wr.reserve(lists, written, nl);
     for (uint32_t q = 0; __any(q < nl); q += FW) {  // FW survivors per trip: their gathers and pair terms interleave
       uint32_t b[FW];
       typename Op::Src cnd[FW];
@@ -1450,7 +1476,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_op(StepConsts<N> c, typen
       for (uint32_t w = 0; w < FW; ++w) cnd[w] = Op::load(args, b[w]);
 #pragma unroll
       for (uint32_t w = 0; w < FW; ++w)
-        if (q + w < nl) wr.put(lists, written + q + w, b[w]);
+        wr.put(written + q + w, b[w], q + w < nl);
 #pragma unroll
       for (uint32_t w = 0; w < FW; ++w) op.add_bf(c, cnd[w], q + w < nl);
     }
@@ -1515,7 +1541,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_op(StepConsts<N> c, typen
     }
   }
   flush();
-  lists.count[i] = wr.finish(lists, written);
+  lists.count[i] = wr.finish(written);
   op.end(c, args, i);
 }
 
@@ -1687,6 +1713,10 @@ __global__ __launch_bounds__(BLOCK) void k_finalise_predict(StepConsts<N> c, con
   const uint32_t a = blockIdx.x * BLOCK + threadIdx.x;
   if (a >= c.n) return;
   const uint8_t ty = c.hasObstacles ? type[a] : uint8_t(0);
+  if (c.slabOn && (ty & TYPE_GHOST)) {  // (see k_predict)
+    key[a] = DEAD_KEY;
+    return;
+  }
   vec4<N> p = pos4[a], v = vel4[a];
   if (ty == 0) {
     finalise_one<N>(c, pstar[a], p, v);
@@ -1696,6 +1726,7 @@ __global__ __launch_bounds__(BLOCK) void k_finalise_predict(StepConsts<N> c, con
   pstar[a] = predict_one<N>(c, p, v, ty, wells, k);
   if (!(ty & 1)) vel4[a] = v;
   key[a] = k;
+  if (!slab_stays(c, k)) return;
   uint32_t before, rank;
   wave_bucket_atomic(min(k, c.tableN), [&](uint32_t b, uint32_t cnt) { return atomicAdd(&count[b], cnt); }, before, rank);
 }
