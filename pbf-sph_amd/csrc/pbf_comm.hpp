@@ -45,6 +45,20 @@ struct pbf_comm {
 
 namespace pbf {
 
+// RCCL only works when it and this library drive the SAME HIP runtime.  A process that loads libpbf_hip.so (linked
+// against ROCm's libamdhip64) and then PyTorch (which ships a libamdhip64 of its own, and the librccl bound to it) holds
+// two: ncclCommInitRank then fails with "unhandled cuda error" somewhere inside.  Refuse with the reason instead:
+// the runtime this library's HIP calls resolve to must be the one librccl's resolve to.
+inline bool comm_same_hip_runtime(pbf_comm *c) {
+  Dl_info mine{}, theirs{};
+  void *rcclHip = dlsym(c->lib, "hipGetDeviceCount");  // searched in librccl and ITS dependencies
+  if (!rcclHip || !dladdr(rcclHip, &theirs) || !dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &mine)) return true;
+  if (!mine.dli_fname || !theirs.dli_fname || std::strcmp(mine.dli_fname, theirs.dli_fname) == 0) return true;
+  c->err = std::string("two HIP runtimes in this process: libpbf_hip.so uses ") + mine.dli_fname + ", the loaded librccl uses " +
+           theirs.dli_fname + " — load the hosting framework (e.g. import torch) BEFORE libpbf_hip.so, or run without it";
+  return false;
+}
+
 inline bool comm_load_rccl(pbf_comm *c) {
   const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
   for (const char *n : names)  // a copy the process already holds (PyTorch ships its own) wins: one RCCL per process
@@ -61,6 +75,7 @@ inline bool comm_load_rccl(pbf_comm *c) {
     if (!fp) c->err = std::string("librccl lacks ") + name;
     return fp != nullptr;
   };
+  if (!comm_same_hip_runtime(c)) return false;
   return sym("ncclGetUniqueId", c->fGetUniqueId) && sym("ncclCommInitRank", c->fCommInitRank) &&
          sym("ncclCommDestroy", c->fCommDestroy) && sym("ncclSend", c->fSend) && sym("ncclRecv", c->fRecv) &&
          sym("ncclGroupStart", c->fGroupStart) && sym("ncclGroupEnd", c->fGroupEnd) &&
@@ -85,11 +100,20 @@ inline int comm_exchange(pbf_comm *c, hipStream_t stream, const void *sendL, siz
   if (c->comm) {
     ncclResult_t r;
     if ((r = c->fGroupStart()) != ncclSuccess) return comm_fail(c, "ncclGroupStart", r);
-    if (nRL && (r = c->fRecv(recvL, nRL, ncclUint8, c->rank - 1, c->comm, stream)) != ncclSuccess) return comm_fail(c, "ncclRecv", r);
-    if (nRR && (r = c->fRecv(recvR, nRR, ncclUint8, c->rank + 1, c->comm, stream)) != ncclSuccess) return comm_fail(c, "ncclRecv", r);
-    if (nSL && (r = c->fSend(sendL, nSL, ncclUint8, c->rank - 1, c->comm, stream)) != ncclSuccess) return comm_fail(c, "ncclSend", r);
-    if (nSR && (r = c->fSend(sendR, nSR, ncclUint8, c->rank + 1, c->comm, stream)) != ncclSuccess) return comm_fail(c, "ncclSend", r);
-    if ((r = c->fGroupEnd()) != ncclSuccess) return comm_fail(c, "ncclGroupEnd", r);
+    // a failing send / recv must not leave the group open (the next RCCL call on this thread would be queued into it):
+    // remember the first error, stop posting, ALWAYS close the group
+    const char *what = nullptr;
+    ncclResult_t bad = ncclSuccess;
+    auto post = [&](const char *name, ncclResult_t res) {
+      if (res != ncclSuccess && !what) what = name, bad = res;
+    };
+    if (nRL && !what) post("ncclRecv", c->fRecv(recvL, nRL, ncclUint8, c->rank - 1, c->comm, stream));
+    if (nRR && !what) post("ncclRecv", c->fRecv(recvR, nRR, ncclUint8, c->rank + 1, c->comm, stream));
+    if (nSL && !what) post("ncclSend", c->fSend(sendL, nSL, ncclUint8, c->rank - 1, c->comm, stream));
+    if (nSR && !what) post("ncclSend", c->fSend(sendR, nSR, ncclUint8, c->rank + 1, c->comm, stream));
+    r = c->fGroupEnd();
+    if (what) return comm_fail(c, what, bad);
+    if (r != ncclSuccess) return comm_fail(c, "ncclGroupEnd", r);
     return PBF_OK;
   }
   if (!c->fn) {

@@ -27,6 +27,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <set>
@@ -81,6 +82,69 @@ struct InProcessLink {  // rank's view: mailboxes to / from both neighbours
     if (nSR && k->toRight) k->toRight->drained();
     return 0;
   }
+};
+
+// A fixed crew of host threads, one per slab, that runs f(0) .. f(n - 1) concurrently on every run() call.
+class Workers {
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable go_, done_;
+  std::function<void(size_t)> task_;
+  std::vector<std::string> errs_;
+  uint64_t epoch_ = 0;
+  size_t pending_ = 0;
+  bool stop_ = false;
+
+public:
+  size_t size() const { return threads_.size(); }
+  void start(size_t n) {
+    shutdown();
+    stop_ = false;
+    errs_.assign(n, std::string());
+    for (size_t g = 0; g < n; ++g)
+      threads_.emplace_back([this, g] {
+        uint64_t seen = 0;
+        for (;;) {
+          std::function<void(size_t)> job;
+          {
+            std::unique_lock<std::mutex> l(m_);
+            go_.wait(l, [&] { return stop_ || epoch_ != seen; });
+            if (stop_) return;
+            seen = epoch_;
+            job = task_;
+          }
+          std::string err;
+          try {
+            job(g);
+          } catch (const std::exception &e) {
+            err = e.what();
+          }
+          std::unique_lock<std::mutex> l(m_);
+          errs_[g] = err;
+          if (--pending_ == 0) done_.notify_all();
+        }
+      });
+  }
+  void run(std::function<void(size_t)> f) {
+    std::unique_lock<std::mutex> l(m_);
+    task_ = std::move(f);
+    pending_ = threads_.size();
+    ++epoch_;
+    go_.notify_all();
+    done_.wait(l, [&] { return pending_ == 0; });
+    for (const auto &e : errs_)
+      if (!e.empty()) throw std::runtime_error(e);
+  }
+  void shutdown() {
+    {
+      std::unique_lock<std::mutex> l(m_);
+      stop_ = true;
+      go_.notify_all();
+    }
+    for (auto &t : threads_) t.join();
+    threads_.clear();
+  }
+  ~Workers() { shutdown(); }
 };
 
 // slab.py recut(): particle-count quantiles of the column histogram, each cut moved by at most `maxMove` columns
@@ -138,20 +202,12 @@ class Solver final : public sph::Solver<T, N, V> {
   bool attached_ = false;
   bool multi() const { return slabs_.size() > 1; }
 
-  template <typename F> void parallel(F &&f) {  // one host thread per device, errors rethrown on the caller's thread
-    std::vector<std::thread> ts;
-    std::vector<std::string> errs(slabs_.size());
-    for (size_t g = 0; g < slabs_.size(); ++g)
-      ts.emplace_back([&, g] {
-        try {
-          f(g);
-        } catch (const std::exception &e) {
-          errs[g] = e.what();
-        }
-      });
-    for (auto &t : ts) t.join();
-    for (const auto &e : errs)
-      if (!e.empty()) throw std::runtime_error(e);
+  // One PERSISTENT host thread per device (round 3: fresh std::threads every step cost ~50 us of creation and join per
+  // step): the workers sleep on a condition variable between tasks; errors are rethrown on the caller's thread.
+  detail::Workers workers_;
+  template <typename F> void parallel(F &&f) {
+    if (workers_.size() != slabs_.size()) workers_.start(slabs_.size());
+    workers_.run(std::function<void(size_t)>(std::forward<F>(f)));
   }
   void checkOn(size_t g, int rc, const char *what) const {
     if (rc < 0) throw std::runtime_error(std::string(what) + " (device " + std::to_string(devices_[g]) + "): " + pbf_last_error(slabs_[g]));
@@ -245,6 +301,7 @@ public:
     }
   }
   ~Solver() override {
+    workers_.shutdown();
     if (slabs_.empty()) pbf_destroy(ctx_);
     for (auto *s : slabs_) pbf_destroy(s);
     for (auto *c : comms_) pbf_comm_destroy(c);

@@ -5,6 +5,7 @@ production transport is RCCL, exercised by bench.py --gpus N on a multi-GPU node
   * HIP slabs == oracle-engine slabs, bit for bit (same protocol, same ordering, same arithmetic);
   * HIP slabs == single-GPU run to summation-order noise; nothing lost or duplicated;
   * 2 + 2K exchange rounds per step; load-balance re-cuts agree with the CPU twin; RCCL communicator set-up."""
+import json
 import os
 
 import numpy as np
@@ -170,3 +171,55 @@ def test_rccl_communicator_single_rank(torch_first):
     r = subprocess.run([sys.executable, "-c", RCCL_SCRIPT.format(root=root, torch_first=torch_first)], capture_output=True,
                        text=True, timeout=600, env=dict(os.environ, NCCL_DEBUG="WARN"))
     assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+BAD_ORDER_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+from conftest import load_package
+pkg = load_package()
+a = pkg.Solver(h=0.1)          # libpbf_hip.so (and ROCm's HIP runtime) first ...
+import torch                   # ... then PyTorch with the HIP runtime and librccl it bundles
+torch.zeros(1, device="cuda")
+from pbf_sph_amd import slab
+sc, side = pkg.scene_dambreak(8192)
+a.upload(**sc)
+try:
+    slab.CSlabSolver(a, None, None, 0, 1, [0, 1024], 1024, 1024, transport="rccl")
+    print("CREATED")
+except RuntimeError as e:
+    print("REFUSED:", e)
+"""
+
+
+def test_rccl_refuses_a_second_hip_runtime():
+    """libpbf_hip.so loaded BEFORE PyTorch leaves two HIP runtimes in the process and RCCL then fails
+    somewhere inside ncclCommInitRank.  The library now checks that the librccl it binds drives the same libamdhip64 as
+    its own HIP calls and refuses with the reason (or, where the image's PyTorch shares ROCm's runtime, simply works)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", BAD_ORDER_SCRIPT.format(root=root)], capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert "CREATED" in r.stdout or ("REFUSED:" in r.stdout and "two HIP runtimes" in r.stdout), out[-3000:]
+    assert "unhandled cuda error" not in out
+
+
+def test_rccl_send_recv_between_two_gpus():
+    """The ncclSend / ncclRecv path itself needs two GPUs (RCCL refuses two ranks on one device): bench.py --gpus 2 — its
+    own two ranks, one per GPU, ONE 256 K column cut into two slabs, ghost exchange over xGMI inside pbf_slab_step — and
+    its built-in conservation check (no particle lost or duplicated across the cut).  Skips itself on a one-GPU box."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (the driver's multi-GPU node); this box has %d" % torch.cuda.device_count())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "5",
+                        "--settle-to", "40", "--particles", "262144", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert d["n_gpus"] == 2 and d["config"]["particles"] == 250000
+    assert "ncclSend/ncclRecv" in d["config"]["parallelism"] and "10 exchange rounds per step" in d["config"]["parallelism"]
