@@ -129,6 +129,7 @@ _SIGS = {
     "pbf_reset_stage_times": (C.c_int, [C.c_void_p]),
     "pbf_surface": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(C.c_uint64)]),
     "pbf_download_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pbf_map_mesh": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "pbf_read_lattice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pbf_reserve": (C.c_int, [C.c_void_p, C.c_size_t]),
     "pbf_slab_configure": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),

@@ -119,7 +119,10 @@ struct pbf_ctx {
   size_t reserve = 0;        // pbf_reserve: capacity kept for migrants and ghost copies
   uint32_t nOwned = 0, sentL = 0, sentR = 0, gotL = 0, gotR = 0;
   // marching cubes (pbf_surface)
-  DevBuf latticePN, latticeC, mcCounts, mcOffsets, mcSums, meshV, meshN, meshC;
+  DevBuf latticePN, latticeC, mcCounts, mcOffsets, mcSums, meshV, meshN, meshC, mcNear;
+  void *meshHost = nullptr;  // pinned staging of the last mesh (pbf_map_mesh)
+  size_t meshHostCap = 0;
+  bool meshStaged = false;
   uint64_t mcSample[3] = {0, 0, 0};
   uint64_t mcTriangles = 0;
   DevBuf qpos;               // 8-byte quantised pStar for the list build (k_build_lists_q)
@@ -152,8 +155,8 @@ struct pbf_ctx {
   // list-driven lambda; 8 (default) = the quantised build with lambda riding on its flushes (k_build_lists_op: one launch,
   // no list read for lambda).  (Round 1's intermediate build kernels, values 1-3, are gone.)
   int splitBuild = 8;
-  int pipeline = -1;         // option "pipeline": software-pipelined list readers (bit-identical either way); -1 = auto:
-                             // fp64 only (measured at 1 M: fp64 -1.3 %, fp32 +3 % — fp32's readers are VALU-issue bound)
+  int pipeline = -1;         // option "pipeline": software-pipelined list readers (bit-identical either way); -1 = auto = off
+                             // (measured at 1 M, round 3: fp32 +3 %, fp64 +2.4 % per step with it)
   int coop = 0;              // option "coop": 0 = one lane per particle (bit-exact), 2 / 4 / 8 = lanes sharing a particle's
                              // list with a wave-shuffle reduction (k_gather_from_lists_coop; rounding-level differences)
   bool fusePredict = true;   // option "fuse_predict": pbf_steps runs finalise(t) + predict(t + 1) as one kernel
@@ -161,6 +164,7 @@ struct pbf_ctx {
   // option "overlap_diffuse" (default on): inside pbf_step the colour diffusion — memory-latency bound, 85 % of its wave
   // time parked — runs on a side stream beside the VALU-bound solver iterations (nothing else touches colours)
   bool overlapDiffuse = true;
+  bool overlapDiffuseForced = false;  // option / env set explicitly: no size heuristic
   hipStream_t sideStream = nullptr;
   hipEvent_t evFork = nullptr, evJoin = nullptr;
   bool diffusePending = false;
@@ -596,7 +600,9 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
           default: break;
         }
       }
-      if (ctx->pipeline < 0 ? sizeof(N) == 8 : ctx->pipeline != 0)
+      // (auto = off: with round 3's trimmed fp64 sqrt / divides the plain reader wins in fp64 too — 2.05 vs 2.10 ms per step
+      // at 1 M; in round 2, on the compiler's IEEE forms, the pipelined one had been 1.3 % ahead there)
+      if (ctx->pipeline > 0)
         hipLaunchKernelGGL((k_gather_from_lists<N, Op, true>), g, b, 0, ctx->stream, c, args, key, table, ls);
       else
         hipLaunchKernelGGL((k_gather_from_lists<N, Op, false>), g, b, 0, ctx->stream, c, args, key, table, ls);
@@ -660,7 +666,10 @@ template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p, bool 
   typename DiffuseOp<N>::Args args{ctx->col4[s].as<const vec4<N>>(), ctx->col4[d].as<vec4<N>>(),
                                    ctx->type[s].as<const uint8_t>()};
   const bool timed = (ctx->desc.flags & PBF_FLAG_STAGE_TIMING) != 0 && ((ctx->timingMask >> ST_DIFFUSE) & 1u) != 0;
-  overlap = overlap && ctx->overlapDiffuse && ctx->cellDiffuse && !(ctx->desc.flags & PBF_FLAG_NO_LDS) && !timed;
+  // beside the solver iterations only where that pays: at 1 M particles -2.2 % per step, at 256 K +1.4 % (the side stream's
+  // one-workgroup-per-CU launch is then longer than the iteration it hides behind) — measured, profiles/r03_matrix.txt
+  overlap = overlap && ctx->overlapDiffuse && ctx->cellDiffuse && !(ctx->desc.flags & PBF_FLAG_NO_LDS) && !timed &&
+            (ctx->overlapDiffuseForced || ctx->n >= (size_t(1) << 19));
   ctx->omegaValid = false;  // (the per-cell sums may be parked in pStar's idle Jacobi partner)
   StageTimer t(ctx, ST_DIFFUSE);
   if (ctx->cellDiffuse && !(ctx->desc.flags & PBF_FLAG_NO_LDS)) {
@@ -959,7 +968,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   else if (n == "cell_diffuse") ctx->cellDiffuse = value != 0;
   else if (n == "pipeline") ctx->pipeline = int(value);
   else if (n == "graph") ctx->graphMode = int(value);
-  else if (n == "overlap_diffuse") ctx->overlapDiffuse = value != 0;
+  else if (n == "overlap_diffuse") ctx->overlapDiffuse = value != 0, ctx->overlapDiffuseForced = true;
   else if (n == "coop") {
     if (value != 0 && value != 2 && value != 4 && value != 8) return fail(ctx, PBF_ERR_INVALID, "coop must be 0, 2, 4 or 8");
     ctx->coop = int(value);
@@ -1024,7 +1033,7 @@ int pbf_create(const pbf_desc *desc, pbf_ctx **out) {
   if (const char *e = std::getenv("PBF_REUSE_LISTS")) ctx->reuseLists = std::atoi(e) != 0;
   if (const char *e = std::getenv("PBF_SPLIT_BUILD")) ctx->splitBuild = std::atoi(e);
   if (const char *e = std::getenv("PBF_LIST_MAX")) ctx->listMax = uint32_t(std::atoi(e));
-  if (const char *e = std::getenv("PBF_OVERLAP_DIFFUSE")) ctx->overlapDiffuse = std::atoi(e) != 0;
+  if (const char *e = std::getenv("PBF_OVERLAP_DIFFUSE")) ctx->overlapDiffuse = std::atoi(e) != 0, ctx->overlapDiffuseForced = true;
   if (const char *e = std::getenv("PBF_PIPELINE")) ctx->pipeline = std::atoi(e);
   if (const char *e = std::getenv("PBF_GRAPH")) ctx->graphMode = std::atoi(e);
   if (const char *e = std::getenv("PBF_COOP")) {
@@ -1063,7 +1072,7 @@ void pbf_destroy(pbf_ctx *ctx) {
                    &ctx->id[0],   &ctx->id[1],   &ctx->type[0], &ctx->type[1], &ctx->key[0],   &ctx->key[1],
                    &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2], &ctx->count, &ctx->table,   &ctx->blockSums,
                    &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl, &ctx->bigCells,
-                   &ctx->latticePN, &ctx->latticeC, &ctx->mcCounts, &ctx->mcOffsets, &ctx->mcSums, &ctx->meshV, &ctx->meshN,
+                   &ctx->latticePN, &ctx->latticeC, &ctx->mcCounts, &ctx->mcOffsets, &ctx->mcSums, &ctx->mcNear, &ctx->meshV, &ctx->meshN,
                    &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR, &ctx->colHist, &ctx->wireSend[0], &ctx->wireSend[1], &ctx->wireRecv[0], &ctx->wireRecv[1], &ctx->wireGhost[0], &ctx->wireGhost[1], &ctx->diffSum, &ctx->diffCnt};
   for (DevBuf *b : all)
     if (b->p) (void)hipFree(b->p);
@@ -1073,6 +1082,7 @@ void pbf_destroy(pbf_ctx *ctx) {
   if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
   if (ctx->sideStream) (void)hipStreamDestroy(ctx->sideStream);
   if (ctx->hostCounts) (void)hipHostFree(ctx->hostCounts);
+  if (ctx->meshHost) (void)hipHostFree(ctx->meshHost);
   if (ctx->regPtr) (void)hipHostUnregister(ctx->regPtr);
   if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -2100,12 +2110,19 @@ template <typename N> int surface_impl(pbf_ctx *ctx, const pbf_params *p, const 
   const int s = ctx->cur;
   if (int rc = ensure(ctx, ctx->latticePN, latticeN * sizeof(vec4<N>))) return rc;
   if (int rc = ensure(ctx, ctx->latticeC, latticeN * sizeof(vec4<N>))) return rc;
-  hipLaunchKernelGGL((k_mc_field<N>), grid_for(latticeN), dim3(BLOCK), 0, ctx->stream, m, ctx->table.as<const uint32_t>(),
+  // cells within one cell of an occupied one (most lattice nodes sit in empty space and skip their 27-cell gather)
+  if (int rc = ensure(ctx, ctx->mcNear, size_t(c.tableN) + 64)) return rc;
+  HIPCHK(ctx, hipMemsetAsync(ctx->mcNear.p, 0, size_t(c.tableN), ctx->stream));
+  hipLaunchKernelGGL(k_mc_mark_near, grid_for(c.tableN), dim3(BLOCK), 0, ctx->stream, c.tableN,
+                     make_uint3(m.extent[0], m.extent[1], m.extent[2]), ctx->table.as<const uint32_t>(), ctx->mcNear.as<uint8_t>());
+  const uint64_t nodeBlocks = uint64_t((m.sample[0] + 3) / 4) * ((m.sample[1] + 3) / 4) * ((m.sample[2] + 3) / 4);
+  hipLaunchKernelGGL((k_mc_field<N>), grid_for(nodeBlocks * 64), dim3(BLOCK), 0, ctx->stream, m, ctx->table.as<const uint32_t>(),
                      ctx->pos4[s].as<const vec4<N>>(), ctx->col4[s].as<const vec4<N>>(), ctx->type[s].as<const uint8_t>(),
-                     ctx->latticePN.as<vec4<N>>(), ctx->latticeC.as<vec4<N>>());
+                     ctx->mcNear.as<const uint8_t>(), ctx->latticePN.as<vec4<N>>(), ctx->latticeC.as<vec4<N>>());
   LAUNCH_CHECK(ctx);
   *nTriangles = 0;
   ctx->mcTriangles = 0;
+  ctx->meshStaged = false;
   if (m.sample[0] < 2 || m.sample[1] < 2 || m.sample[2] < 2) return PBF_OK;
   const uint64_t march64 = uint64_t(m.sample[0] - 1) * (m.sample[1] - 1) * (m.sample[2] - 1);
   const uint32_t marchVolume = uint32_t(march64), len = marchVolume + 1;
@@ -2158,6 +2175,33 @@ int pbf_download_mesh(pbf_ctx *ctx, void *vs, void *ns, void *cs) {
   if (ns) HIPCHK(ctx, hipMemcpyAsync(ns, ctx->meshN.p, n * 9 * e, hipMemcpyDeviceToHost, ctx->stream));
   if (cs) HIPCHK(ctx, hipMemcpyAsync(cs, ctx->meshC.p, n * 12 * e, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PBF_OK;
+}
+
+int pbf_map_mesh(pbf_ctx *ctx, const void **vs, const void **ns, const void **cs) {
+  if (!ctx || !vs || !ns || !cs) return PBF_ERR_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = ctx->mcTriangles, e = ctx->fp64 ? 8 : 4;
+  *vs = *ns = *cs = nullptr;
+  if (n == 0) return PBF_OK;
+  const size_t bv = n * 9 * e, bc = n * 12 * e, total = 2 * bv + bc;
+  if (ctx->meshHostCap < total) {
+    if (ctx->meshHost) (void)hipHostFree(ctx->meshHost);
+    ctx->meshHost = nullptr, ctx->meshHostCap = 0;
+    const size_t want = total + total / 4 + 4096;
+    HIPCHK(ctx, hipHostMalloc(&ctx->meshHost, want, hipHostMallocDefault));
+    ctx->meshHostCap = want;
+    ctx->meshStaged = false;
+  }
+  char *h = static_cast<char *>(ctx->meshHost);
+  if (!ctx->meshStaged) {
+    HIPCHK(ctx, hipMemcpyAsync(h, ctx->meshV.p, bv, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h + bv, ctx->meshN.p, bv, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h + 2 * bv, ctx->meshC.p, bc, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->meshStaged = true;
+  }
+  *vs = h, *ns = h + bv, *cs = h + 2 * bv;
   return PBF_OK;
 }
 

@@ -9,6 +9,7 @@
 // --resident times the device-resident loop; the surface's case tables are our own, so the vertex
 // count need not equal the reference's triangle for triangle.
 #include <hip/hip_runtime_api.h>
+#include <malloc.h>
 
 #include <algorithm>
 #include <chrono>
@@ -181,6 +182,13 @@ template <typename N> int run(sph::driver::Args args, const std::vector<int> &de
 }  // namespace
 
 int main(int argc, char *argv[]) {
+  // advance() returns the mesh by value (src/sph.hpp:114-125): three freshly allocated vectors per frame — 54 MB at 1 M
+  // particles — which `result = solver.advance(...)` (benchmark.cpp:33,47) frees again one frame later.  Left alone, glibc
+  // hands the freed top of the heap back to the system every frame (the trim threshold follows the mmap threshold) and
+  // the next frame's vectors fault every page in again: ~2 ms per frame of page faults.  Keep the memory instead.
+  mallopt(M_MMAP_THRESHOLD, 32 << 20);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_TOP_PAD, 128 << 20);
   sph::driver::Args args(200, "./out_{impl}_{type}_{iter}");
   if (!args.parse(argc, argv)) return EXIT_SUCCESS;  // the reference exits 0 after help / parse errors too
   if (args.impl != "hip") {

@@ -26,6 +26,8 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -202,6 +204,23 @@ class Solver final : public sph::Solver<T, N, V> {
   bool attached_ = false;
   bool multi() const { return slabs_.size() > 1; }
 
+  // PBF_SHIM_TIMING=1: mean host time of advance()'s phases, printed by the destructor (diagnostic)
+  struct Phases {
+    bool on = std::getenv("PBF_SHIM_TIMING") != nullptr;
+    double ms[5] = {0, 0, 0, 0, 0};
+    uint64_t frames = 0;
+  } phase_;
+  struct PhaseClock {
+    Phases &p;
+    std::chrono::steady_clock::time_point t;
+    explicit PhaseClock(Phases &ph) : p(ph), t(std::chrono::steady_clock::now()) { p.frames += p.on; }
+    void lap(int k) {
+      if (!p.on) return;
+      const auto n = std::chrono::steady_clock::now();
+      p.ms[k] += std::chrono::duration<double, std::milli>(n - t).count();
+      t = n;
+    }
+  };
   // One PERSISTENT host thread per device (round 3: fresh std::threads every step cost ~50 us of creation and join per
   // step): the workers sleep on a condition variable between tasks; errors are rethrown on the caller's thread.
   detail::Workers workers_;
@@ -301,6 +320,11 @@ public:
     }
   }
   ~Solver() override {
+    if (phase_.on && phase_.frames)
+      std::fprintf(stderr, "advance() phases, mean ms over %llu frames: upload %.3f | step %.3f | surface kernels + mesh DMA %.3f | "
+                           "particle download %.3f | mesh vectors (rest) %.3f\n", (unsigned long long)phase_.frames,
+                   phase_.ms[0] / phase_.frames, phase_.ms[1] / phase_.frames, phase_.ms[2] / phase_.frames,
+                   phase_.ms[3] / phase_.frames, phase_.ms[4] / phase_.frames);
     workers_.shutdown();
     if (slabs_.empty()) pbf_destroy(ctx_);
     for (auto *s : slabs_) pbf_destroy(s);
@@ -442,26 +466,81 @@ public:
       download(xs);
       return {};
     }
+    PhaseClock clk(phase_);
     upload(xs);
+    clk.lap(0);
     step(config, scene, 1);
+    if (phase_.on) sync();
+    clk.lap(1);
     sph::Result<T, N, V> result;
     if (!scene.queries.empty()) result.queries = query(config, scene);
-    if (config.surface) result.mesh = surface(config, scene);  // ompsph.hpp:277-477
-    download(xs);
+    if (config.surface) {  // ompsph.hpp:277-477
+      // the mesh lands in page-locked staging (one DMA); its three vectors are then built on host threads WHILE the
+      // particles travel back over PCIe
+      MeshCopy copy(*this, config, scene, result.mesh);
+      clk.lap(2);
+      download(xs);
+      clk.lap(3);
+      copy.join();
+      clk.lap(4);
+    } else {
+      download(xs);
+      clk.lap(3);
+    }
     return result;
   }
 
   // Marching-cubes surface of the state the last step left (reference: config.surface, ompsph.hpp:277-477).
   sph::ColouredMesh<N, V> surface(const sph::SphParams<T, N, V> &config, const sph::Scene<T, N, V> &scene = {}) {
-    const pbf_params p = params(config, scene);
-    const pbf_mc_params mc{double(config.surface->resolution), double(config.surface->isolevel),
-                           double(config.surface->particleSize), double(config.surface->particleInfluence)};
-    uint64_t triangles = 0;
-    check(pbf_surface(ctx_, &p, &mc, &triangles), "pbf_surface");
-    sph::ColouredMesh<N, V> mesh(size_t(triangles) * 3);
-    check(pbf_download_mesh(ctx_, mesh.vs.data(), mesh.ns.data(), mesh.cs.data()), "pbf_download_mesh");
+    sph::ColouredMesh<N, V> mesh;
+    MeshCopy(*this, config, scene, mesh).join();
     return mesh;
   }
+
+private:
+  // pbf_surface + the mesh hand-over.  ColouredMesh(size) would zero-fill 54 MB (1 M particles) that a pageable
+  // device-to-host copy then overwrites at a few GB/s: 11 ms per frame in round 2.  Instead: ONE DMA into the library's
+  // page-locked staging (pbf_map_mesh), then the three vectors are range-assigned from it (no fill), two of them on threads
+  // of their own and the third by join() — so the caller can do something useful (the particle download) in between.
+  struct MeshCopy {
+    sph::ColouredMesh<N, V> &mesh;
+    const V<3> *v3 = nullptr, *n3 = nullptr;
+    const V<4> *c4 = nullptr;
+    size_t nv = 0;
+    std::thread tv, tn;
+    MeshCopy(Solver &s, const sph::SphParams<T, N, V> &config, const sph::Scene<T, N, V> &scene, sph::ColouredMesh<N, V> &out)
+        : mesh(out) {
+      const pbf_params p = s.params(config, scene);
+      const pbf_mc_params mc{double(config.surface->resolution), double(config.surface->isolevel),
+                             double(config.surface->particleSize), double(config.surface->particleInfluence)};
+      uint64_t triangles = 0;
+      s.check(pbf_surface(s.ctx_, &p, &mc, &triangles), "pbf_surface");
+      const void *pv = nullptr, *pn = nullptr, *pc = nullptr;
+      s.check(pbf_map_mesh(s.ctx_, &pv, &pn, &pc), "pbf_map_mesh");
+      nv = size_t(triangles) * 3;
+      v3 = static_cast<const V<3> *>(pv), n3 = static_cast<const V<3> *>(pn), c4 = static_cast<const V<4> *>(pc);
+      if (nv >= (size_t(1) << 16)) {  // (small meshes — the stock 18 K-particle run: a thread costs more than the copy)
+        tv = std::thread([this] { mesh.vs.assign(v3, v3 + nv); });
+        tn = std::thread([this] { mesh.ns.assign(n3, n3 + nv); });
+      }
+    }
+    void join() {
+      if (nv == 0) return;
+      if (tv.joinable()) {
+        mesh.cs.assign(c4, c4 + nv);
+        tv.join(), tn.join();
+      } else {
+        mesh.vs.assign(v3, v3 + nv), mesh.ns.assign(n3, n3 + nv), mesh.cs.assign(c4, c4 + nv);
+      }
+      nv = 0;
+    }
+    ~MeshCopy() {
+      if (tv.joinable()) tv.join();
+      if (tn.joinable()) tn.join();
+    }
+  };
+
+public:
 
 private:
   // ids of the fluid particles in the cell that holds each query point (ompsph.hpp:167-186);
