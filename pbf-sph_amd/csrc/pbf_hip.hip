@@ -2111,14 +2111,14 @@ template <typename N> int surface_impl(pbf_ctx *ctx, const pbf_params *p, const 
   if (int rc = ensure(ctx, ctx->latticePN, latticeN * sizeof(vec4<N>))) return rc;
   if (int rc = ensure(ctx, ctx->latticeC, latticeN * sizeof(vec4<N>))) return rc;
   // cells within one cell of an occupied one (most lattice nodes sit in empty space and skip their 27-cell gather)
-  if (int rc = ensure(ctx, ctx->mcNear, size_t(c.tableN) + 64)) return rc;
-  HIPCHK(ctx, hipMemsetAsync(ctx->mcNear.p, 0, size_t(c.tableN), ctx->stream));
+  if (int rc = ensure(ctx, ctx->mcNear, (size_t(c.tableN) + 64) * 4)) return rc;
+  HIPCHK(ctx, hipMemsetAsync(ctx->mcNear.p, 0, size_t(c.tableN) * 4, ctx->stream));
   hipLaunchKernelGGL(k_mc_mark_near, grid_for(c.tableN), dim3(BLOCK), 0, ctx->stream, c.tableN,
-                     make_uint3(m.extent[0], m.extent[1], m.extent[2]), ctx->table.as<const uint32_t>(), ctx->mcNear.as<uint8_t>());
+                     make_uint3(m.extent[0], m.extent[1], m.extent[2]), ctx->table.as<const uint32_t>(), ctx->mcNear.as<uint32_t>());
   const uint64_t nodeBlocks = uint64_t((m.sample[0] + 3) / 4) * ((m.sample[1] + 3) / 4) * ((m.sample[2] + 3) / 4);
   hipLaunchKernelGGL((k_mc_field<N>), grid_for(nodeBlocks * 64), dim3(BLOCK), 0, ctx->stream, m, ctx->table.as<const uint32_t>(),
                      ctx->pos4[s].as<const vec4<N>>(), ctx->col4[s].as<const vec4<N>>(), ctx->type[s].as<const uint8_t>(),
-                     ctx->mcNear.as<const uint8_t>(), ctx->latticePN.as<vec4<N>>(), ctx->latticeC.as<vec4<N>>());
+                     ctx->mcNear.as<const uint32_t>(), ctx->latticePN.as<vec4<N>>(), ctx->latticeC.as<vec4<N>>());
   LAUNCH_CHECK(ctx);
   *nTriangles = 0;
   ctx->mcTriangles = 0;

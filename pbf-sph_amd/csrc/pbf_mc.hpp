@@ -30,30 +30,41 @@ template <typename N> struct McConsts {
   uint32_t hasObstacles;
 };
 
-// near[code] = 1 for every grid cell within one cell of an occupied one (round 3).  The lattice of the 1 M dam-break has
-// 7.2 M nodes of which ~85 % sit in empty space, and each of them used to look 27 cells up (54 table loads) only to find them
-// empty: 2.2 ms.  A node inside the grid whose own cell is not flagged has no candidate at all — its clamped 27 cells
-// (ompsph.hpp:305-310) are exactly the in-range cells within one of its own — and goes straight to the (v = 0) tail.
+// nearMask[code]: bit k = 1 iff slot k of that cell's 27-slot walk (k = (dz * 3 + dy) * 3 + dx, the reference's order,
+// coordinates clamped to the grid so that slots may repeat a cell at the domain faces — ompsph.hpp:305-330) holds a
+// non-empty cell (round 3).  The lattice of the 1 M dam-break has 7.2 M nodes; the settled fluid is a sheet, so most of a
+// node's 27 cells are empty and each used to cost two dependent table loads to find that out: 2.2 ms.  Scatter form: every
+// occupied cell c' sets, for each offset d, the bit of the cells c with clamp(c + d) = c' — per axis c' - d when that is
+// inside the grid, and c' itself when the clamp folds d back onto it (d = -1 at coordinate 0, d = +1 at the last one).
 __global__ __launch_bounds__(BLOCK) void k_mc_mark_near(uint32_t tableN, uint3 extent, const uint32_t *__restrict__ table,
-                                                        uint8_t *__restrict__ nearFlag) {
+                                                        uint32_t *__restrict__ nearMask) {
   const uint32_t code = blockIdx.x * BLOCK + threadIdx.x;
   if (code + 1u >= tableN) return;  // (the table's last cell is empty by definition, sph.hpp:208)
   if (table[code + 1u] == table[code]) return;
-  const int cx = int(compact10(code)), cy = int(compact10(code >> 1)), cz = int(compact10(code >> 2));
-  for (int dz = -1; dz <= 1; ++dz)
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int x = cx + dx, y = cy + dy, z = cz + dz;
-        if (x < 0 || y < 0 || z < 0 || x >= int(extent.x) || y >= int(extent.y) || z >= int(extent.z)) continue;
-        nearFlag[morton_encode(uint32_t(x), uint32_t(y), uint32_t(z))] = 1;  // (benign race: everybody writes 1)
-      }
+  const int c[3] = {int(compact10(code)), int(compact10(code >> 1)), int(compact10(code >> 2))};
+  const int ext[3] = {int(extent.x), int(extent.y), int(extent.z)};
+  if (c[0] >= ext[0] || c[1] >= ext[1] || c[2] >= ext[2]) return;  // (a code below tableN outside the box: never a node's cell)
+  for (int k = 0; k < 27; ++k) {
+    const int d[3] = {k % 3 - 1, (k / 3) % 3 - 1, k / 9 - 1};
+    int sol[3][2], ns[3];
+    for (int a = 0; a < 3; ++a) {
+      ns[a] = 0;
+      const int v = c[a] - d[a];
+      if (v >= 0 && v < ext[a]) sol[a][ns[a]++] = v;
+      if ((d[a] == -1 && c[a] == 0) || (d[a] == 1 && c[a] == ext[a] - 1)) sol[a][ns[a]++] = c[a];
+    }
+    for (int i = 0; i < ns[0]; ++i)
+      for (int j = 0; j < ns[1]; ++j)
+        for (int l = 0; l < ns[2]; ++l)
+          atomicOr(&nearMask[morton_encode(uint32_t(sol[0][i]), uint32_t(sol[1][j]), uint32_t(sol[2][l]))], 1u << k);
+  }
 }
 
 template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_mc_field(McConsts<N> m, const uint32_t *__restrict__ table,
                                                     const vec4<N> *__restrict__ pos4,
                                                     const vec4<N> *__restrict__ col4,
-                                                    const uint8_t *__restrict__ type, const uint8_t *__restrict__ nearFlag,
+                                                    const uint8_t *__restrict__ type, const uint32_t *__restrict__ nearMask,
                                                     vec4<N> *__restrict__ latticePN,
                                                     vec4<N> *__restrict__ latticeC) {
   // lane -> node: 8 consecutive lanes take a 2 x 2 x 2 block of nodes (one grid cell at the stock resolution 2: the same 27
@@ -85,12 +96,12 @@ __global__ __launch_bounds__(BLOCK) void k_mc_field(McConsts<N> m, const uint32_
   N v = 0, nx = 0, ny = 0, nz = 0, cr = 0, cg = 0, cb = 0, ca = 0;
   uint32_t nNeighbours = 0;
   const N ninf = (-m.particleInfluence) * m.particleSize;
-  // a node inside the grid far from every particle: nothing to gather (the tail below gives it the same bits as before)
+  // which of the 27 slots hold a non-empty cell (a node whose cell lies outside the grid looks every slot up itself)
   const N t2loose = (m.threshold * m.threshold) * N(1.000001);
+  const bool inflHalf = m.particleInfluence == N(0.5);
   const bool inside = zX < m.extent[0] && zY < m.extent[1] && zZ < m.extent[2];
-  const bool empty = inside && nearFlag[morton_encode(zX, zY, zZ)] == 0;
-  // candidates in the reference's order; four loads in flight per trip (a load per trip left the kernel waiting a memory
-  // latency per candidate: 1.8 ms at 1 M particles), the three cells of an x row looked up together
+  uint32_t slots = inside ? nearMask[morton_encode(zX, zY, zZ)] : 0x07FFFFFFu;
+  // candidates in the reference's order, four loads in flight per trip
   auto fold = [&](const vec4<N> &p, uint32_t b) {
     const N lx = p.x - ax, ly = p.y - ay, lz = p.z - az;
     const N d2 = lx * lx + ly * ly + lz * lz;
@@ -100,44 +111,44 @@ __global__ __launch_bounds__(BLOCK) void k_mc_field(McConsts<N> m, const uint32_
     if (!(d2 < t2loose)) return;
     const N len = sqrt(d2);
     if (!(len < m.threshold)) return;
-    const N denominator = pow(len, m.particleInfluence);
-    v += (m.particleSize / denominator);
-    nx = nx + (lx / denominator) * ninf, ny = ny + (ly / denominator) * ninf, nz = nz + (lz / denominator) * ninf;
+    // The hits' arithmetic is what the kernel spends its time on (a libm-style pow and four IEEE divides per hit: ~130
+    // VALU).  The stock influence 0.5 (sph.hpp:183) makes pow(len, 0.5) a square root — correctly rounded, i.e. at least
+    // as close to the reference's glm::pow as the device's pow is —, and the four quotients share ONE refined reciprocal
+    // with an exact-residual correction each (div_ranged: the IEEE quotient for operands in the normal range, which a
+    // hit's are unless it sits on the node itself: then, wave-wide, the compiler's divide).
+    const N denominator = inflHalf ? sqrt(len) : pow(len, m.particleInfluence);
+    if (__any(!(denominator > N(1e-18)))) {
+      v += (m.particleSize / denominator);
+      nx = nx + (lx / denominator) * ninf, ny = ny + (ly / denominator) * ninf, nz = nz + (lz / denominator) * ninf;
+    } else {
+      v += div_ranged(m.particleSize, denominator);
+      nx = nx + div_ranged(lx, denominator) * ninf, ny = ny + div_ranged(ly, denominator) * ninf,
+      nz = nz + div_ranged(lz, denominator) * ninf;
+    }
     const vec4<N> c = col4[b];
     cr += c.x, cg += c.y, cb += c.z, ca += c.w;
     nNeighbours++;
   };
-#pragma unroll 1
-  for (int dz = empty ? 3 : 0; dz < 3; ++dz)
-#pragma unroll 1
-    for (int dy = 0; dy < 3; ++dy) {
-      uint32_t s0[3], e0[3];
+  while (slots) {  // ascending slot number = the reference's order (x fastest, then y, then z)
+    const int k = __builtin_ctz(slots);
+    slots &= slots - 1u;
+    const uint32_t off = morton_encode(xs[k % 3], ys[(k / 3) % 3], zs[k / 9]);
+    if (off >= m.tableN) continue;
+    const uint32_t s0 = table[off], e0 = (off + 1u) < m.tableN ? table[off + 1u] : s0;
+    for (uint32_t b = s0; b < e0; b += 4u) {
+      vec4<N> p[4];
+      bool ok[4];
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const uint32_t off = morton_encode(xs[dx], ys[dy], zs[dz]);
-        s0[dx] = e0[dx] = 0;
-        if (off < m.tableN) {
-          s0[dx] = table[off];
-          e0[dx] = (off + 1u) < m.tableN ? table[off + 1u] : s0[dx];
-        }
+      for (uint32_t w = 0; w < 4; ++w) {
+        const uint32_t bw = min(b + w, e0 - 1u);  // a tail slot re-reads the last candidate and is masked
+        ok[w] = b + w < e0 && !(m.hasObstacles && type[bw] != 0);
+        p[w] = pos4[bw];
       }
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        for (uint32_t b = s0[dx]; b < e0[dx]; b += 4u) {
-          vec4<N> p[4];
-          bool ok[4];
-#pragma unroll
-          for (uint32_t w = 0; w < 4; ++w) {
-            const uint32_t bw = min(b + w, e0[dx] - 1u);  // a tail slot re-reads the last candidate and is masked
-            ok[w] = b + w < e0[dx] && !(m.hasObstacles && type[bw] != 0);
-            p[w] = pos4[bw];
-          }
-#pragma unroll
-          for (uint32_t w = 0; w < 4; ++w)
-            if (ok[w]) fold(p[w], b + w);
-        }
-      }
+      for (uint32_t w = 0; w < 4; ++w)
+        if (ok[w]) fold(p[w], b + w);
     }
+  }
   const N inv = N(1) / sqrt(nx * nx + ny * ny + nz * nz);
   latticePN[idx] = make_vec4<N>(v, nx * inv, ny * inv, nz * inv);
   const N nn = N(nNeighbours);

@@ -500,14 +500,14 @@ public:
 private:
   // pbf_surface + the mesh hand-over.  ColouredMesh(size) would zero-fill 54 MB (1 M particles) that a pageable
   // device-to-host copy then overwrites at a few GB/s: 11 ms per frame in round 2.  Instead: ONE DMA into the library's
-  // page-locked staging (pbf_map_mesh), then the three vectors are range-assigned from it (no fill), two of them on threads
-  // of their own and the third by join() — so the caller can do something useful (the particle download) in between.
+  // page-locked staging (pbf_map_mesh), then the three vectors are range-assigned from it (no fill), each on a thread of its
+  // own — so the caller can do something useful (the particle download) until join().
   struct MeshCopy {
     sph::ColouredMesh<N, V> &mesh;
     const V<3> *v3 = nullptr, *n3 = nullptr;
     const V<4> *c4 = nullptr;
     size_t nv = 0;
-    std::thread tv, tn;
+    std::thread tv, tn, tc;
     MeshCopy(Solver &s, const sph::SphParams<T, N, V> &config, const sph::Scene<T, N, V> &scene, sph::ColouredMesh<N, V> &out)
         : mesh(out) {
       const pbf_params p = s.params(config, scene);
@@ -522,13 +522,13 @@ private:
       if (nv >= (size_t(1) << 16)) {  // (small meshes — the stock 18 K-particle run: a thread costs more than the copy)
         tv = std::thread([this] { mesh.vs.assign(v3, v3 + nv); });
         tn = std::thread([this] { mesh.ns.assign(n3, n3 + nv); });
+        tc = std::thread([this] { mesh.cs.assign(c4, c4 + nv); });
       }
     }
     void join() {
       if (nv == 0) return;
       if (tv.joinable()) {
-        mesh.cs.assign(c4, c4 + nv);
-        tv.join(), tn.join();
+        tv.join(), tn.join(), tc.join();
       } else {
         mesh.vs.assign(v3, v3 + nv), mesh.ns.assign(n3, n3 + nv), mesh.cs.assign(c4, c4 + nv);
       }
@@ -537,6 +537,7 @@ private:
     ~MeshCopy() {
       if (tv.joinable()) tv.join();
       if (tn.joinable()) tn.join();
+      if (tc.joinable()) tc.join();
     }
   };
 
