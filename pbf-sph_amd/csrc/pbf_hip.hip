@@ -2090,39 +2090,86 @@ namespace {
 template <typename N> int surface_impl(pbf_ctx *ctx, const pbf_params *p, const pbf_mc_params *mp, uint64_t *nTriangles) {
   StepConsts<N> c;
   if (int rc = make_consts<N>(ctx, p, c)) return rc;
-  if (ctx->slabConfigured) return fail(ctx, PBF_ERR_INVALID, "pbf_surface is not available in slab mode yet");
+  // Slab mode (after pbf_slab_step; the copies of the neighbours' boundary columns are still in the arrays): every rank
+  // extracts the part of the GLOBAL lattice whose nodes lie in its own cell columns — the ghost layer supplies exactly the
+  // 27-cell neighbourhoods those nodes need — after refreshing the copies' colours (the owners diffused them during the
+  // step), receives the one node plane its last cubes share with the right-hand neighbour, and emits its cubes'
+  // triangles: the ranks' meshes, concatenated in rank order, ARE the single-device mesh's cube order (x-major).
+  const bool slab = ctx->slabConfigured && ctx->comm && ctx->comm->nranks > 1;
+  if (ctx->slabConfigured && !slab) return fail(ctx, PBF_ERR_STATE, "pbf_surface in slab mode needs pbf_slab_attach");
+  if (slab && !ctx->ghostsPending) return fail(ctx, PBF_ERR_STATE, "pbf_surface in slab mode must follow pbf_slab_step directly");
   McConsts<N> m;
   m.scale = c.scale, m.res = N(mp->resolution), m.isolevel = N(mp->isolevel), m.particleSize = N(mp->particle_size);
   m.particleInfluence = N(mp->particle_influence);
   m.step = c.h / m.res;           // ompsph.hpp:291
   m.threshold = c.h * c.scale * 1;  // ompsph.hpp:293
-  uint64_t latticeN = 1;
+  uint64_t sampleG[3];
   for (int k = 0; k < 3; ++k) {
     m.minExtent[k] = c.minExtent[k];
-    m.extent[k] = uint32_t(ctx->extent[k]);
-    const uint64_t smp = uint64_t(std::floor(N(ctx->extent[k]) * m.res)) + 1;  // ompsph.hpp:283-284
-    m.sample[k] = uint32_t(smp);
-    ctx->mcSample[k] = smp;
-    latticeN *= smp;
+    m.extent[k] = uint32_t(ctx->extent[k]);   // (global: make_consts leaves ctx->extent untouched by the slab frame)
+    sampleG[k] = uint64_t(std::floor(N(ctx->extent[k]) * m.res)) + 1;  // ompsph.hpp:283-284
+    m.sample[k] = uint32_t(sampleG[k]);
   }
+  m.xoff = 0, m.nodeX0 = 0, m.planes = m.sample[0];
+  bool hasRight = false;
+  if (slab) {
+    const int r = ctx->comm->rank, nr = ctx->comm->nranks;
+    // first global node x whose cell column floor(x / res) is >= col: the smallest integer x with x / res >= col (in N,
+    // like the kernel's own division)
+    auto first_node = [&](uint32_t col) {
+      uint64_t x = uint64_t(std::ceil(N(col) * m.res));
+      while (x > 0 && uint64_t(N(x - 1) / m.res) >= col) --x;
+      while (uint64_t(N(x) / m.res) < col) ++x;
+      return std::min<uint64_t>(x, sampleG[0]);
+    };
+    const uint64_t x0 = r > 0 ? first_node(ctx->cuts[r]) : 0, x1 = r + 1 < nr ? first_node(ctx->cuts[r + 1]) : sampleG[0];
+    hasRight = r + 1 < nr && x1 < sampleG[0];
+    m.xoff = ctx->xoff, m.nodeX0 = uint32_t(x0), m.planes = uint32_t(x1 - x0);
+    m.sample[0] = m.planes + (hasRight ? 1u : 0u);
+    // the owners' diffused colours -> their copies on the neighbours (one more field round; the copies' pStar is current)
+    const size_t fb = sizeof(vec4<N>);
+    vec4<N> *col = ctx->col4[ctx->cur].as<vec4<N>>();
+    if (int rc = slab_pack<N>(ctx, ctx->wireSend[0].p, ctx->wireSend[1].p, col)) return rc;
+    if (int rc = exchange(ctx, ctx->sentL * fb, ctx->sentR * fb, ctx->gotL * fb, ctx->gotR * fb)) return rc;
+    if (int rc = slab_unpack<N>(ctx, ctx->wireRecv[0].p, ctx->wireRecv[1].p, col)) return rc;
+  }
+  for (int k = 0; k < 3; ++k) ctx->mcSample[k] = m.sample[k];
+  const uint64_t planeN = uint64_t(m.sample[1]) * m.sample[2];
+  const uint64_t latticeN = uint64_t(m.sample[0]) * planeN;
   if (latticeN >= (uint64_t(1) << 31)) return fail(ctx, PBF_ERR_INVALID, "surface lattice too large (resolution x extent)");
   m.tableN = c.tableN, m.hasObstacles = c.hasObstacles;
   const int s = ctx->cur;
-  if (int rc = ensure(ctx, ctx->latticePN, latticeN * sizeof(vec4<N>))) return rc;
-  if (int rc = ensure(ctx, ctx->latticeC, latticeN * sizeof(vec4<N>))) return rc;
-  // cells within one cell of an occupied one (most lattice nodes sit in empty space and skip their 27-cell gather)
-  if (int rc = ensure(ctx, ctx->mcNear, (size_t(c.tableN) + 64) * 4)) return rc;
-  HIPCHK(ctx, hipMemsetAsync(ctx->mcNear.p, 0, size_t(c.tableN) * 4, ctx->stream));
-  hipLaunchKernelGGL(k_mc_mark_near, grid_for(c.tableN), dim3(BLOCK), 0, ctx->stream, c.tableN,
-                     make_uint3(m.extent[0], m.extent[1], m.extent[2]), ctx->table.as<const uint32_t>(), ctx->mcNear.as<uint32_t>());
-  const uint64_t nodeBlocks = uint64_t((m.sample[0] + 3) / 4) * ((m.sample[1] + 3) / 4) * ((m.sample[2] + 3) / 4);
-  hipLaunchKernelGGL((k_mc_field<N>), grid_for(nodeBlocks * 64), dim3(BLOCK), 0, ctx->stream, m, ctx->table.as<const uint32_t>(),
-                     ctx->pos4[s].as<const vec4<N>>(), ctx->col4[s].as<const vec4<N>>(), ctx->type[s].as<const uint8_t>(),
-                     ctx->mcNear.as<const uint32_t>(), ctx->latticePN.as<vec4<N>>(), ctx->latticeC.as<vec4<N>>());
-  LAUNCH_CHECK(ctx);
+  if (int rc = ensure(ctx, ctx->latticePN, (latticeN + 1) * sizeof(vec4<N>))) return rc;
+  if (int rc = ensure(ctx, ctx->latticeC, (latticeN + 1) * sizeof(vec4<N>))) return rc;
   *nTriangles = 0;
   ctx->mcTriangles = 0;
   ctx->meshStaged = false;
+  if (m.planes) {
+    // which of a cell's 27 slots hold particles (most lattice nodes sit in empty space and skip their gather)
+    if (int rc = ensure(ctx, ctx->mcNear, (size_t(c.tableN) + 64) * 4)) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->mcNear.p, 0, size_t(c.tableN) * 4, ctx->stream));
+    hipLaunchKernelGGL(k_mc_mark_near, grid_for(c.tableN), dim3(BLOCK), 0, ctx->stream, c.tableN,
+                       make_uint3(m.extent[0], m.extent[1], m.extent[2]), m.xoff, ctx->table.as<const uint32_t>(),
+                       ctx->mcNear.as<uint32_t>());
+    const uint64_t nodeBlocks = uint64_t((m.planes + 3) / 4) * ((m.sample[1] + 3) / 4) * ((m.sample[2] + 3) / 4);
+    hipLaunchKernelGGL((k_mc_field<N>), grid_for(nodeBlocks * 64), dim3(BLOCK), 0, ctx->stream, m, ctx->table.as<const uint32_t>(),
+                       ctx->pos4[s].as<const vec4<N>>(), ctx->pstar[ctx->pcur].as<const vec4<N>>(), ctx->col4[s].as<const vec4<N>>(),
+                       ctx->type[s].as<const uint8_t>(), ctx->mcNear.as<const uint32_t>(), ctx->latticePN.as<vec4<N>>(),
+                       ctx->latticeC.as<vec4<N>>());
+    LAUNCH_CHECK(ctx);
+  }
+  if (slab) {  // my first node plane -> the left neighbour's extra plane (two rounds: {v, normal} and colours)
+    const size_t pb = size_t(planeN) * sizeof(vec4<N>);
+    const bool sendLeft = ctx->comm->rank > 0 && m.planes > 0;
+    for (DevBuf *lat : {&ctx->latticePN, &ctx->latticeC}) {
+      uint8_t *base = lat->as<uint8_t>();
+      if (int rc = comm_exchange(ctx->comm, ctx->stream, base, sendLeft ? pb : 0, nullptr, 0, nullptr, 0,
+                                 base + size_t(m.planes) * pb, hasRight ? pb : 0)) {
+        ctx->err = "slab surface exchange: " + ctx->comm->err;
+        return rc;
+      }
+    }
+  }
   if (m.sample[0] < 2 || m.sample[1] < 2 || m.sample[2] < 2) return PBF_OK;
   const uint64_t march64 = uint64_t(m.sample[0] - 1) * (m.sample[1] - 1) * (m.sample[2] - 1);
   const uint32_t marchVolume = uint32_t(march64), len = marchVolume + 1;
@@ -2160,7 +2207,7 @@ extern "C" {
 
 int pbf_surface(pbf_ctx *ctx, const pbf_params *params, const pbf_mc_params *mc, uint64_t *n_triangles) {
   if (int rc = check(ctx, params, true)) return rc;
-  if (ctx->ghostsPending) return fail(ctx, PBF_ERR_INVALID, "pbf_surface is not available in slab mode yet");
+
   if (!mc || !n_triangles) return fail(ctx, PBF_ERR_INVALID, "NULL argument");
   if (!(mc->resolution > 0)) return fail(ctx, PBF_ERR_INVALID, "resolution must be > 0");
   return DISPATCH(ctx, surface_impl, ctx, params, mc, n_triangles);

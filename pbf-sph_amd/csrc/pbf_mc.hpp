@@ -28,6 +28,10 @@ template <typename N> struct McConsts {
   uint32_t sample[3];
   uint32_t tableN;
   uint32_t hasObstacles;
+  // slab mode (pbf_surface after pbf_slab_step; all zero / equal on a single device): this rank's lattice holds the node
+  // planes x = nodeX0 .. nodeX0 + sample[0] - 1 of the global lattice (the last one, for every rank but the rightmost,
+  // received from the right-hand neighbour), `planes` of them computed here; keys live in the rank's x frame
+  uint32_t xoff, nodeX0, planes;
 };
 
 // nearMask[code]: bit k = 1 iff slot k of that cell's 27-slot walk (k = (dz * 3 + dy) * 3 + dx, the reference's order,
@@ -36,12 +40,14 @@ template <typename N> struct McConsts {
 // node's 27 cells are empty and each used to cost two dependent table loads to find that out: 2.2 ms.  Scatter form: every
 // occupied cell c' sets, for each offset d, the bit of the cells c with clamp(c + d) = c' — per axis c' - d when that is
 // inside the grid, and c' itself when the clamp folds d back onto it (d = -1 at coordinate 0, d = +1 at the last one).
-__global__ __launch_bounds__(BLOCK) void k_mc_mark_near(uint32_t tableN, uint3 extent, const uint32_t *__restrict__ table,
+__global__ __launch_bounds__(BLOCK) void k_mc_mark_near(uint32_t tableN, uint3 extent, uint32_t xoff,
+                                                        const uint32_t *__restrict__ table,
                                                         uint32_t *__restrict__ nearMask) {
   const uint32_t code = blockIdx.x * BLOCK + threadIdx.x;
   if (code + 1u >= tableN) return;  // (the table's last cell is empty by definition, sph.hpp:208)
   if (table[code + 1u] == table[code]) return;
-  const int c[3] = {int(compact10(code)), int(compact10(code >> 1)), int(compact10(code >> 2))};
+  // (x in GLOBAL cell coordinates: the clamp folds happen at the global faces; slab keys carry x - xoff)
+  const int c[3] = {int(compact10(code) + xoff), int(compact10(code >> 1)), int(compact10(code >> 2))};
   const int ext[3] = {int(extent.x), int(extent.y), int(extent.z)};
   if (c[0] >= ext[0] || c[1] >= ext[1] || c[2] >= ext[2]) return;  // (a code below tableN outside the box: never a node's cell)
   for (int k = 0; k < 27; ++k) {
@@ -56,20 +62,23 @@ __global__ __launch_bounds__(BLOCK) void k_mc_mark_near(uint32_t tableN, uint3 e
     for (int i = 0; i < ns[0]; ++i)
       for (int j = 0; j < ns[1]; ++j)
         for (int l = 0; l < ns[2]; ++l)
-          atomicOr(&nearMask[morton_encode(uint32_t(sol[0][i]), uint32_t(sol[1][j]), uint32_t(sol[2][l]))], 1u << k);
+          if (sol[0][i] >= int(xoff)) {
+            const uint32_t at = morton_encode(uint32_t(sol[0][i]) - xoff, uint32_t(sol[1][j]), uint32_t(sol[2][l]));
+            if (at < tableN) atomicOr(&nearMask[at], 1u << k);  // (a slab's table ends at its right ghost column)
+          }
   }
 }
 
 template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_mc_field(McConsts<N> m, const uint32_t *__restrict__ table,
-                                                    const vec4<N> *__restrict__ pos4,
+                                                    const vec4<N> *__restrict__ pos4, const vec4<N> *__restrict__ pstar,
                                                     const vec4<N> *__restrict__ col4,
                                                     const uint8_t *__restrict__ type, const uint32_t *__restrict__ nearMask,
                                                     vec4<N> *__restrict__ latticePN,
                                                     vec4<N> *__restrict__ latticeC) {
   // lane -> node: 8 consecutive lanes take a 2 x 2 x 2 block of nodes (one grid cell at the stock resolution 2: the same 27
   // cells, so their table and candidate loads coalesce into one request), 64 lanes a 4 x 4 x 4 block
-  const uint32_t sx = m.sample[0], sy = m.sample[1], sz = m.sample[2];
+  const uint32_t sx = m.planes, sy = m.sample[1], sz = m.sample[2];  // (slab mode: the received plane is not computed here)
   const uint32_t bx = (sx + 3u) / 4u, by = (sy + 3u) / 4u, bz = (sz + 3u) / 4u;
   const uint32_t t = blockIdx.x * BLOCK + threadIdx.x, blk = t >> 6, l = t & 63u;
   if (blk >= bx * by * bz) return;
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(BLOCK) void k_mc_field(McConsts<N> m, const uint32_
                  z = (blk % bz) * 4u + ((l >> 3) & 1u) * 2u + (l & 1u);
   if (x >= sx || y >= sy || z >= sz) return;
   const uint32_t idx = (x * sy + y) * sz + z;  // index3d (curves.h:17-19)
-  const N px = N(x), py = N(y), pz = N(z);
+  const N px = N(x + m.nodeX0), py = N(y), pz = N(z);
   const N ax = (m.minExtent[0] + (px * m.step)) * m.scale, ay = (m.minExtent[1] + (py * m.step)) * m.scale,
           az = (m.minExtent[2] + (pz * m.step)) * m.scale;
   // the node's cell (ompsph.hpp:293-298); coordinates pass through the 10-bit Morton encode / decode
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(BLOCK) void k_mc_field(McConsts<N> m, const uint32_
   const N t2loose = (m.threshold * m.threshold) * N(1.000001);
   const bool inflHalf = m.particleInfluence == N(0.5);
   const bool inside = zX < m.extent[0] && zY < m.extent[1] && zZ < m.extent[2];
-  uint32_t slots = inside ? nearMask[morton_encode(zX, zY, zZ)] : 0x07FFFFFFu;
+  uint32_t slots = inside ? nearMask[morton_encode(zX - m.xoff, zY, zZ)] : 0x07FFFFFFu;
   // candidates in the reference's order, four loads in flight per trip
   auto fold = [&](const vec4<N> &p, uint32_t b) {
     const N lx = p.x - ax, ly = p.y - ay, lz = p.z - az;
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(BLOCK) void k_mc_field(McConsts<N> m, const uint32_
   while (slots) {  // ascending slot number = the reference's order (x fastest, then y, then z)
     const int k = __builtin_ctz(slots);
     slots &= slots - 1u;
-    const uint32_t off = morton_encode(xs[k % 3], ys[(k / 3) % 3], zs[k / 9]);
+    const uint32_t off = morton_encode(xs[k % 3] - m.xoff, ys[(k / 3) % 3], zs[k / 9]);
     if (off >= m.tableN) continue;
     const uint32_t s0 = table[off], e0 = (off + 1u) < m.tableN ? table[off + 1u] : s0;
     for (uint32_t b = s0; b < e0; b += 4u) {
@@ -141,8 +150,13 @@ __global__ __launch_bounds__(BLOCK) void k_mc_field(McConsts<N> m, const uint32_
 #pragma unroll
       for (uint32_t w = 0; w < 4; ++w) {
         const uint32_t bw = min(b + w, e0 - 1u);  // a tail slot re-reads the last candidate and is masked
-        ok[w] = b + w < e0 && !(m.hasObstacles && type[bw] != 0);
+        const uint8_t ty = m.hasObstacles ? type[bw] : uint8_t(0);
+        ok[w] = b + w < e0 && !(ty & TYPE_OBSTACLE);
         p[w] = pos4[bw];
+        if (ty & TYPE_GHOST) {  // a neighbouring slab's particle: its copy carries pStar, and position = pStar * scale
+          const vec4<N> q = pstar[bw];  // (ompsph.hpp:260, the very product the owner's finalise stored)
+          p[w] = make_vec4<N>(q.x * m.scale, q.y * m.scale, q.z * m.scale, N(0));
+        }
       }
 #pragma unroll
       for (uint32_t w = 0; w < 4; ++w)
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(BLOCK) void k_mc_emit(McConsts<N> m, uint32_t march
     auto mix = [&](N a, N b) { return a * (N(1) - wgt) + b * wgt; };   // glm::mix
     auto coord = [&](uint32_t c, int ax) { return (m.minExtent[ax] + (N(c) * m.step)) * m.scale; };
     const vec4<N> pf = latticePN[node[f]], pt = latticePN[node[t]], cf = latticeC[node[f]], ct = latticeC[node[t]];
-    outV[3 * w + 0] = mix(coord(px + CX[f], 0), coord(px + CX[t], 0));
+    outV[3 * w + 0] = mix(coord(px + m.nodeX0 + CX[f], 0), coord(px + m.nodeX0 + CX[t], 0));
     outV[3 * w + 1] = mix(coord(py + CY[f], 1), coord(py + CY[t], 1));
     outV[3 * w + 2] = mix(coord(pz + CZ[f], 2), coord(pz + CZ[t], 2));
     outN[3 * w + 0] = mix(pf.y, pt.y), outN[3 * w + 1] = mix(pf.z, pt.z), outN[3 * w + 2] = mix(pf.w, pt.w);

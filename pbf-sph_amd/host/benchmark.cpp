@@ -99,10 +99,10 @@ template <typename N> int run(sph::driver::Args args, const std::vector<int> &de
 
   uint32_t flags = (args.fastMath ? PBF_FLAG_FAST_MATH : 0u) | (args.verbose ? PBF_FLAG_STAGE_TIMING : 0u);
   const bool slabbed = devices.size() > 1;
-  if (slabbed) {  // x-slabs: device-resident stepping; the surface is a single-device feature
-    if (!args.resident || args.surface) std::cout << "Slab mode (" << devices.size() << " slabs): --resident --no-surface implied" << std::endl;
-    args.resident = true, args.surface = false;
-    param.surface.reset();
+  if (slabbed) {  // x-slabs: device-resident stepping (the surface: every slab its own node planes, concatenated)
+    if (!args.resident) std::cout << "Slab mode (" << devices.size() << " slabs): --resident implied" << std::endl;
+    else std::cout << "Slab mode (" << devices.size() << " slabs)" << std::endl;
+    args.resident = true;
   }
   sph::hip_impl::Solver<T, N> solver(N(0.1), devices, flags);
   sph::Result<T, N, sph::vec> result;

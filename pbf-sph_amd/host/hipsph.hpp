@@ -459,12 +459,13 @@ public:
       return {};
     }
     if (multi()) {
-      if (config.surface || !scene.queries.empty())
-        throw std::runtime_error("surface / queries are single-device features (pbf_surface is not available in slab mode)");
+      if (!scene.queries.empty()) throw std::runtime_error("queries are a single-device feature");
       upload(xs, &config);
       step(config, scene, 1);
+      sph::Result<T, N, V> result;
+      if (config.surface) result.mesh = surface(config, scene);  // every slab its part of the lattice, concatenated
       download(xs);
-      return {};
+      return result;
     }
     PhaseClock clk(phase_);
     upload(xs);
@@ -491,9 +492,33 @@ public:
   }
 
   // Marching-cubes surface of the state the last step left (reference: config.surface, ompsph.hpp:277-477).
+  // Several devices: every slab extracts the cubes of its own node planes (pbf_surface is collective there: the slabs
+  // refresh their copies' colours and hand one node plane to the left), the parts are concatenated in slab order — the
+  // single-device mesh's cube order.
   sph::ColouredMesh<N, V> surface(const sph::SphParams<T, N, V> &config, const sph::Scene<T, N, V> &scene = {}) {
     sph::ColouredMesh<N, V> mesh;
-    MeshCopy(*this, config, scene, mesh).join();
+    if (!multi()) {
+      MeshCopy(*this, config, scene, mesh).join();
+      return mesh;
+    }
+    const pbf_params p = params(config, scene);
+    const pbf_mc_params mc{double(config.surface->resolution), double(config.surface->isolevel),
+                           double(config.surface->particleSize), double(config.surface->particleInfluence)};
+    std::vector<uint64_t> tri(slabs_.size(), 0);
+    parallel([&](size_t g) { checkOn(g, pbf_surface(slabs_[g], &p, &mc, &tri[g]), "pbf_surface"); });
+    size_t total = 0;
+    for (uint64_t t : tri) total += size_t(t) * 3;
+    mesh.vs.reserve(total), mesh.ns.reserve(total), mesh.cs.reserve(total);
+    for (size_t g = 0; g < slabs_.size(); ++g) {
+      const void *pv = nullptr, *pn = nullptr, *pc = nullptr;
+      checkOn(g, pbf_map_mesh(slabs_[g], &pv, &pn, &pc), "pbf_map_mesh");
+      const size_t nv = size_t(tri[g]) * 3;
+      if (!nv) continue;
+      const V<3> *v3 = static_cast<const V<3> *>(pv), *n3 = static_cast<const V<3> *>(pn);
+      const V<4> *c4 = static_cast<const V<4> *>(pc);
+      mesh.vs.insert(mesh.vs.end(), v3, v3 + nv), mesh.ns.insert(mesh.ns.end(), n3, n3 + nv);
+      mesh.cs.insert(mesh.cs.end(), c4, c4 + nv);
+    }
     return mesh;
   }
 

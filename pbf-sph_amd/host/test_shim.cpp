@@ -183,6 +183,44 @@ int main(int argc, char **argv) {
     two.advance(dparam, {}, c);
     CHECK("multi_device_advance", c.size() == dparticles.size(), "size %zu", c.size());
   }
+  {  // the surface across slabs (round 3): every slab extracts the cubes of its own node planes — ghost layer for the
+     // 27-cell neighbourhoods, the owners' diffused colours refreshed on the copies, one node plane handed to the left —
+     // and the parts concatenated in slab order are the single-device mesh.  K = 0 (no delta-p: positions cannot differ by a
+     // summation order): vertices and normals bit for bit, colours to rounding (a cell's particles may sit in another
+     // order on a slab); K = 4: the same surface up to the solver's summation noise.
+    auto [dparam, dparticles] = sph::damBreakConfig<T, N, sph::vec>(8192, 0, N(500));
+    dparam.surface = sph::McParams<N>{N(2.0f), N(100), N(25), N(0.5)};
+    auto colour = dparticles;
+    for (size_t i = 0; i < colour.size(); ++i) colour[i].colour = V4(N(i % 7) / 7, N(i % 5) / 5, N(i % 3) / 3, 1);
+    for (int iteration : {0, 4}) {
+      dparam.iteration = size_t(iteration);
+      auto a = colour, b = colour;
+      sph::hip_impl::Solver<T, N> slabs(N(0.1), std::vector<int>{0, 0, 0});
+      sph::hip_impl::Solver<T, N> one(N(0.1));
+      sph::Result<T, N, sph::vec> ra, rb;
+      for (int f = 0; f < 3; ++f) ra = slabs.advance(dparam, {}, a), rb = one.advance(dparam, {}, b);
+      const auto &ma = ra.mesh, &mb = rb.mesh;
+      if (iteration == 0) {
+        bool same = ma.vs.size() == mb.vs.size() && ma.vs.size() > 3000 && ma.ns.size() == mb.ns.size() && ma.cs.size() == mb.cs.size();
+        double worstC = 0;
+        size_t badN = 0;
+        for (size_t i = 0; same && i < ma.vs.size(); ++i) {
+          same = ma.vs[i] == mb.vs[i];
+          // (normals: NaN == NaN counts as equal — nodes without a neighbour carry 0 / 0)
+          auto eq = [](N x, N y) { return x == y || (x != x && y != y); };
+          badN += !(eq(ma.ns[i].x, mb.ns[i].x) && eq(ma.ns[i].y, mb.ns[i].y) && eq(ma.ns[i].z, mb.ns[i].z));
+          worstC = std::max({worstC, double(std::fabs(ma.cs[i].x - mb.cs[i].x)), double(std::fabs(ma.cs[i].y - mb.cs[i].y)),
+                             double(std::fabs(ma.cs[i].z - mb.cs[i].z)), double(std::fabs(ma.cs[i].w - mb.cs[i].w))});
+        }
+        CHECK("multi_device_surface_exact", same && badN <= ma.vs.size() / 1000 && worstC <= 1e-5, "vertices %zu vs %zu, normals off %zu, colours off by %g",
+              ma.vs.size(), mb.vs.size(), badN, worstC);
+      } else {
+        const double ra_n = double(ma.vs.size()), rb_n = double(mb.vs.size());
+        CHECK("multi_device_surface_solved", rb_n > 3000 && std::fabs(ra_n - rb_n) <= 0.02 * rb_n + 60, "vertices %zu vs %zu", ma.vs.size(),
+              mb.vs.size());
+      }
+    }
+  }
   std::printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
 }

@@ -75,7 +75,7 @@ def test_cpp_shim_sources_drains_queries():
     r = subprocess.run([os.path.join(ROOT, "pbf-sph_amd", "test_shim")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout + r.stderr
     for name in ("sources_count", "sources_accumulate", "drains", "queries", "depleted", "advance_equals_resident",
-                 "multi_device_slabs", "multi_device_advance"):
+                 "multi_device_slabs", "multi_device_advance", "multi_device_surface_exact", "multi_device_surface_solved"):
         assert f"ok {name}" in r.stdout, r.stdout
 
 

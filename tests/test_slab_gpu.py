@@ -179,8 +179,8 @@ sys.path.insert(0, os.path.join({root!r}, "tests"))
 from conftest import load_package
 pkg = load_package()
 a = pkg.Solver(h=0.1)          # libpbf_hip.so (and ROCm's HIP runtime) first ...
-import torch                   # ... then PyTorch with the HIP runtime and librccl it bundles
-torch.zeros(1, device="cuda")
+import torch                   # ... then PyTorch with the HIP runtime and librccl it bundles (in this order PyTorch's own
+                               # runtime finds no device any more — "No HIP GPUs are available" — so nothing of torch's is used)
 from pbf_sph_amd import slab
 sc, side = pkg.scene_dambreak(8192)
 a.upload(**sc)
