@@ -619,7 +619,10 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
         }
         if (ctx->splitBuild == 8) {  // the op rides on the build
           // (staging depth 32 and four survivors per drain trip: measured best of 16 / 24 / 32 x 2 / 4 / 6 / 8)
-          hipLaunchKernelGGL((k_build_lists_op<N, Op, 4, 32, 4>), g, b, 0, ctx->stream, c, args, Op::src(args), qp, args.type, key, table, nbr_lists(ctx, true));
+#ifndef PBF_BUILD_LMAX
+#define PBF_BUILD_LMAX 32
+#endif
+          hipLaunchKernelGGL((k_build_lists_op<N, Op, 4, PBF_BUILD_LMAX, 4>), g, b, 0, ctx->stream, c, args, Op::src(args), qp, args.type, key, table, nbr_lists(ctx, true));
           LAUNCH_CHECK(ctx);
           return PBF_OK;
         }
@@ -678,11 +681,14 @@ template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p, bool 
     vec4<N> *cellSum = ctx->pstar[other_pstar(ctx)].as<vec4<N>>();
     uint32_t *cellCnt = ctx->nbrCount.as<uint32_t>();
     hipStream_t st = ctx->stream;
-    uint32_t cap = sizeof(vec4<N>) == 16 ? 3072u : 1536u;  // 48 KiB of colours: 216 cells x 14 (7) particles
+    // records in the LDS tile: 48 KiB (fp32) / 96 KiB (fp64) of colours.  (Round 2 gave fp64 the same BYTES, i.e. half the
+    // records — below the p99 of the settled dam-break's halos, 1 800: a third of the bricks fell back to the per-cell
+    // global walk and the fp64 diffusion took 0.43 ms against fp32's 0.13.)
+    uint32_t cap = 3072u;
     // beside the solver iterations: a 32-KiB tile (fp32) leaves room for THREE of the list build's 40-KiB workgroups on
     // the CU instead of two (measured: step -2.6 %; p99 of the settled dam-break's halos is 1 800 records, a fuller
     // brick walks globally)
-    if (overlap && sizeof(vec4<N>) == 16) cap = 2048u;
+    if (overlap) cap = 2048u;  // (fp64: 64 KiB + two of the build's 40-KiB workgroups)
     const size_t lds = Brick<4>::HDR + size_t(cap) * sizeof(vec4<N>);
     uint32_t perCU = uint32_t((160 * 1024) / (lds + 1024));
     if (overlap) {

@@ -134,6 +134,14 @@ constexpr uint32_t NUM_XCD = 8;
 __device__ inline uint32_t xcd_chunk() {
 #ifdef PBF_NO_XCD_MAP
   return blockIdx.x;
+#elif defined(PBF_XCD_STRIPE)
+  // experiment: stripes of PBF_XCD_STRIPE consecutive chunks dealt round robin to the XCDs (locality inside a stripe,
+  // load balance across stripes: list-driven kernels do work in proportion to the local density)
+  constexpr uint32_t S = PBF_XCD_STRIPE;
+  const uint32_t g = gridDim.x, full = g / (NUM_XCD * S) * (NUM_XCD * S), b = blockIdx.x;
+  if (b >= full) return b;
+  const uint32_t k = b % NUM_XCD, j = b / NUM_XCD;
+  return ((j / S) * NUM_XCD + k) * S + j % S;
 #else
   const uint32_t g = gridDim.x, k = blockIdx.x % NUM_XCD, q = g / NUM_XCD, r = g % NUM_XCD;
   return k * q + min(k, r) + blockIdx.x / NUM_XCD;

@@ -4,7 +4,7 @@ for rep in 1 2; do
   for lib in default $(ls $R/pbf-sph_amd/ab/*.so 2>/dev/null); do
     n=$(basename $lib .so)
     if [ "$lib" = default ]; then unset PBF_HIP_LIB; else export PBF_HIP_LIB=$lib; fi
-    python3 $R/bench.py --no-cpu-baseline --steps 100 --warmup 100 > $O/${n}_$rep.json 2> $O/${n}_$rep.err || echo "$n failed"
+    python3 $R/bench.py --no-cpu-baseline --steps 40 --warmup 10 > $O/${n}_$rep.json 2> $O/${n}_$rep.err || echo "$n failed"
     python3 - <<PY
 import json
 d=json.load(open("$O/${n}_$rep.json"))
