@@ -127,6 +127,15 @@ struct pbf_ctx {
   uint64_t mcTriangles = 0;
   DevBuf qpos;               // 8-byte quantised pStar for the list build (k_build_lists_q)
   DevBuf nbrList, nbrCount;  // neighbour lists handed from the lambda launch to the delta launch: NBR_ROWS slots per particle
+  // option "row_major": the iterations' working set also laid out cell-row-major (csrc/pbf_kernels.hpp RowArrays)
+  int rowMajor = 1;           // default ON since round 3: -3 % per step at 1 M, -10 % at 4 M (profiles/r03_matrix.txt)
+  DevBuf rowPstar[2], rowMass, rowQpos, rowXYZ, rowType, rowSlotOf, linCount, linTable, linSums;
+  int rcur = 0;               // which rowPstar buffer is live
+  bool rowsValid = false;     // the row arrays describe this step's sorted set (built by the sort)
+  bool nbrRows = false;       // the current neighbour lists hold ROW slots (built by k_build_rows_op)
+  bool pstarInRows = false;   // the current {pStar, lambda} live in rowPstar[rcur] ONLY: pstar[pcur] is stale (materialise_pstar)
+  bool rowsCurrent = false;   // rowPstar[rcur] holds the current {pStar, lambda} (false once a Morton-path stage has moved on)
+  uint32_t rowShift = 0;      // the row grid is the cube [0, 1 << rowShift)^3
   uint64_t nbrExtraAt = 0;   // ... + behind them a pool of NBR_EXTRA-slot chunks for the particles that need more (NbrLists)
   uint32_t nbrChunks = 0, nbrChunksOpt = 0;
   bool nbrValid = false;     // the lists describe pstar[pcur] as it is now
@@ -453,10 +462,13 @@ template <typename N> int stage_predict(pbf_ctx *ctx, const pbf_params *p) {
   ctx->nbrValid = false;
   ctx->qposValid = false;
   ctx->omegaValid = false;
+  ctx->pstarInRows = false, ctx->rowsValid = false, ctx->rowsCurrent = false;
   ctx->counted = true;
   ctx->countedTableN = c.tableN;
   return PBF_OK;
 }
+
+bool row_mode(const pbf_ctx *ctx);
 
 template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
   // the scatter consumes the histogram k_predict built (atomicSub back to zero): never run it twice
@@ -473,6 +485,41 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLOCK), 0, ctx->stream, sums, nb);
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(BLOCK), 0, ctx->stream, count, len, sums, table);
   const int s = ctx->cur, d = 1 - s;
+  // option "row_major": the box cells' populations in cell-row-major order and their scan (the row table), read off the
+  // Morton table; k_rank_move below then writes the iterations' row-major copy on its way
+  RowArrays<N> row{};
+  ctx->rowsValid = false, ctx->pstarInRows = false, ctx->rowsCurrent = false;
+  if (row_mode(ctx)) {
+    // the cube that holds every cell the Morton table knows: P = 2^(bits of tableN / 3, rounded up)
+    uint32_t pshift = 1;
+    while (pshift < 10 && (uint64_t(1) << (3 * pshift)) < uint64_t(c.tableN)) ++pshift;
+    const size_t ncells = size_t(1) << (3 * pshift), llen = ncells + 1;
+    const uint32_t lnb = uint32_t((llen + SCAN_TILE - 1) / SCAN_TILE);
+    const size_t v = sizeof(vec4<N>);
+    if (int rc = ensure(ctx, ctx->linCount, (ncells + 2 + SCAN_TILE) * 4)) return rc;
+    if (int rc = ensure(ctx, ctx->linTable, (ncells + 2 + SCAN_TILE) * 4)) return rc;
+    if (int rc = ensure(ctx, ctx->linSums, (size_t(lnb) + 2) * 4)) return rc;
+    for (int k = 0; k < 2; ++k)
+      if (int rc = ensure(ctx, ctx->rowPstar[k], ctx->cap * v)) return rc;
+    if (int rc = ensure(ctx, ctx->rowMass, ctx->cap * sizeof(N))) return rc;
+    if (int rc = ensure(ctx, ctx->rowQpos, (ctx->cap + QPOS_PAD) * 8)) return rc;
+    if (int rc = ensure(ctx, ctx->rowXYZ, ctx->cap * 4)) return rc;
+    if (int rc = ensure(ctx, ctx->rowType, ctx->cap)) return rc;
+    if (int rc = ensure(ctx, ctx->rowSlotOf, ctx->cap * 4)) return rc;
+    hipLaunchKernelGGL(k_lin_count, grid_for(ncells + 1), dim3(BLOCK), 0, ctx->stream, c.tableN, pshift, table,
+                       ctx->linCount.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(lnb), dim3(BLOCK), 0, ctx->stream, ctx->linCount.as<const uint32_t>(), uint32_t(llen),
+                       ctx->linSums.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->linSums.as<uint32_t>(), lnb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(lnb), dim3(BLOCK), 0, ctx->stream, ctx->linCount.as<const uint32_t>(), uint32_t(llen),
+                       ctx->linSums.as<const uint32_t>(), ctx->linTable.as<uint32_t>());
+    ctx->rcur = 0;
+    row = RowArrays<N>{ctx->rowPstar[0].as<vec4<N>>(), ctx->rowMass.as<N>(), ctx->rowQpos.as<uint2>(), ctx->rowXYZ.as<uint32_t>(),
+                       ctx->rowType.as<uint8_t>(), ctx->rowSlotOf.as<uint32_t>(), ctx->linTable.as<const uint32_t>(),
+                       ctx->linCount.as<uint32_t>() + ncells + 1, pshift};
+    ctx->rowShift = pshift;
+    ctx->rowsValid = true, ctx->rowsCurrent = true;
+  }
   // brickCtl = {nActive bricks, tickets[kTickets], number of big cells}: zeroed once per step
   HIPCHK(ctx, hipMemsetAsync(ctx->brickCtl.p, 0, (kTickets + 2) * 4, ctx->stream));
   uint32_t *nBig = ctx->brickCtl.as<uint32_t>() + kTickets + 1;
@@ -489,7 +536,7 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
   const size_t nLive = ctx->slabStepMode ? ctx->sortLive : ctx->n;
   hipLaunchKernelGGL((k_rank_move<N>), grid_for(nLive), dim3(BLOCK), 0, ctx->stream, c, uint32_t(nLive), c.tableN,
                      ctx->permTmp.as<const uint32_t>(), table, arrays<N>(ctx, s, s), arrays<N>(ctx, d, d),
-                     ctx->slabActive ? ctx->slotOf.as<uint32_t>() : nullptr, ctx->qpos.as<uint2>());
+                     ctx->slabActive ? ctx->slotOf.as<uint32_t>() : nullptr, ctx->qpos.as<uint2>(), row);
   ctx->n = nLive;
   {  // list of non-empty bricks for the persistent gather kernels (+ fresh tickets)
     const uint32_t home = Brick<kBrickZ>::HOME, nBricks = (c.tableN + home - 1) / home;
@@ -503,6 +550,7 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
   ctx->sorted = true;
   ctx->nbrValid = false;
   ctx->qposValid = true;
+  if (ctx->rowsValid) ctx->pstarInRows = true, ctx->qposValid = false;  // (the sort wrote the row copy only)
   ctx->counted = false;
   return PBF_OK;
 }
@@ -513,6 +561,28 @@ inline int other_pstar(const pbf_ctx *ctx) { return ctx->pcur == 2 ? ctx->cur : 
 // Launch one gather stage.  gatherKind picks the kernel (option "gather" / env PBF_GATHER);
 // PBF_FLAG_NO_LDS always forces the plain per-particle global walk.
 enum GatherMode { GATHER_PLAIN = 0, GATHER_SAVE_LISTS = 1, GATHER_FROM_LISTS = 2 };
+
+// Row-major iterations apply to the default configuration only (neighbour lists, lambda riding on the build, one lane per
+// particle, eager launches); everything else keeps the Morton walk.
+bool row_mode(const pbf_ctx *ctx) {
+  return ctx->rowMajor > 0 && ctx->gatherKind == 1 && ctx->splitBuild == 8 && ctx->coop == 0 && ctx->reuseLists &&
+         !ctx->fuseDiffuse && ctx->graphMode <= 0 &&
+         !(ctx->desc.flags & PBF_FLAG_NO_LDS) && uint64_t(ctx->n) * (ctx->fp64 ? 32u : 16u) <= 0xFFFFFFFFull;
+}
+template <typename N> RowWalk row_walk(pbf_ctx *ctx) {
+  return RowWalk{ctx->linTable.as<const uint32_t>(), ctx->rowXYZ.as<const uint32_t>(), ctx->rowSlotOf.as<const uint32_t>(),
+                 ctx->table.as<const uint32_t>(), ctx->tableN, ctx->rowShift};
+}
+// whoever wants {pStar, lambda} in the Morton-sorted array (stage-level read-backs, the extras, the surface) gets it here
+template <typename N> int materialise_pstar(pbf_ctx *ctx) {
+  if (!ctx->pstarInRows) return PBF_OK;
+  hipLaunchKernelGGL((k_rows_to_morton<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, uint32_t(ctx->n),
+                     ctx->rowPstar[ctx->rcur].as<const vec4<N>>(), ctx->rowSlotOf.as<const uint32_t>(),
+                     ctx->pstar[ctx->pcur].as<vec4<N>>());
+  LAUNCH_CHECK(ctx);
+  ctx->pstarInRows = false;
+  return PBF_OK;
+}
 
 // A zeroed word of brickCtl (the sort stage zeroes them all once per step) for ONE launch: the work ticket of a persistent
 // tile kernel, or the chunk allocator of a list build.  More launches than words since the last sort: re-arm.
@@ -735,6 +805,22 @@ template <typename N> int stage_lambda(pbf_ctx *ctx, const pbf_params *p) {
   const bool lists = (ctx->gatherKind == 1 || ctx->gatherKind == 3) && ctx->reuseLists && !(ctx->desc.flags & PBF_FLAG_NO_LDS);
   const GatherMode save = lists ? GATHER_SAVE_LISTS : GATHER_PLAIN;
   ctx->nbrValid = lists;
+  if (lists && ctx->rowsValid && ctx->rowsCurrent && row_mode(ctx) && !ctx->fuseDiffuseNow) {  // the build + lambda on the row-major copy
+    const dim3 g = grid_for(ctx->n), b(BLOCK);
+    const RowWalk rw = row_walk<N>(ctx);
+    if (ctx->fast) {
+      typename LambdaOp<N, true>::Args a{ctx->rowPstar[ctx->rcur].as<vec4<N>>(), nullptr, ctx->rowType.as<const uint8_t>(), ctx->rowMass.as<const N>()};
+      hipLaunchKernelGGL((k_build_rows_op<N, LambdaOp<N, true>, 4, 32, 4>), g, b, 0, ctx->stream, c, a, ctx->rowQpos.as<const uint2>(), rw, nbr_lists(ctx, true));
+    } else {
+      typename LambdaOp<N, false>::Args a{ctx->rowPstar[ctx->rcur].as<vec4<N>>(), nullptr, ctx->rowType.as<const uint8_t>(), ctx->rowMass.as<const N>()};
+      hipLaunchKernelGGL((k_build_rows_op<N, LambdaOp<N, false>, 4, 32, 4>), g, b, 0, ctx->stream, c, a, ctx->rowQpos.as<const uint2>(), rw, nbr_lists(ctx, true));
+    }
+    LAUNCH_CHECK(ctx);
+    ctx->pstarInRows = true, ctx->nbrRows = true;
+    return PBF_OK;
+  }
+  if (int rc = materialise_pstar<N>(ctx)) return rc;  // (a Morton-path launch after row-major ones: options changed mid-step)
+  ctx->rowsCurrent = false, ctx->nbrRows = false;
   if (lists && ctx->fuseDiffuseNow) {  // pbf_step: the colour diffusion rides on this launch's walk
     ctx->fuseDiffuseNow = false;
     const int d = 1 - s;
@@ -771,8 +857,32 @@ template <typename N> int stage_delta(pbf_ctx *ctx, const pbf_params *p) {
   StepConsts<N> c;
   if (int rc = make_consts<N>(ctx, p, c)) return rc;
   StageTimer t(ctx, ST_DELTA);
+  if (ctx->nbrValid && ctx->nbrRows && ctx->rowsValid && ctx->rowsCurrent) {  // list-driven delta-p on the row-major copy
+    ctx->nbrValid = false, ctx->omegaValid = false;
+    const dim3 g = grid_for(ctx->n), b(BLOCK);
+    const RowWalk rw = row_walk<N>(ctx);
+    const int rin = ctx->rcur, rout = 1 - rin;
+    const NbrLists ls = nbr_lists(ctx, false);
+    const uint32_t *key = ctx->key[ctx->cur].as<const uint32_t>(), *table = ctx->table.as<const uint32_t>();
+    if (ctx->fast) {
+      typename DeltaOp<N, true>::Args a{ctx->rowPstar[rin].as<const vec4<N>>(), ctx->rowPstar[rout].as<vec4<N>>(), ctx->rowType.as<const uint8_t>(), ctx->rowQpos.as<uint2>()};
+      if (ctx->pipeline > 0) hipLaunchKernelGGL((k_gather_from_lists<N, DeltaOp<N, true>, true, true>), g, b, 0, ctx->stream, c, a, key, table, ls, rw);
+      else hipLaunchKernelGGL((k_gather_from_lists<N, DeltaOp<N, true>, false, true>), g, b, 0, ctx->stream, c, a, key, table, ls, rw);
+    } else {
+      typename DeltaOp<N, false>::Args a{ctx->rowPstar[rin].as<const vec4<N>>(), ctx->rowPstar[rout].as<vec4<N>>(), ctx->rowType.as<const uint8_t>(), ctx->rowQpos.as<uint2>()};
+      if (ctx->pipeline > 0) hipLaunchKernelGGL((k_gather_from_lists<N, DeltaOp<N, false>, true, true>), g, b, 0, ctx->stream, c, a, key, table, ls, rw);
+      else hipLaunchKernelGGL((k_gather_from_lists<N, DeltaOp<N, false>, false, true>), g, b, 0, ctx->stream, c, a, key, table, ls, rw);
+    }
+    LAUNCH_CHECK(ctx);
+    ctx->rcur = rout;
+    ctx->pstarInRows = true;
+    ctx->qposValid = false;  // (the Morton-order quantised copy is stale now; the row copy is current)
+    return PBF_OK;
+  }
+  if (int rc = materialise_pstar<N>(ctx)) return rc;
+  ctx->rowsCurrent = false;
   const int s = ctx->cur, in = ctx->pcur, out = other_pstar(ctx);
-  const GatherMode from = ctx->nbrValid ? GATHER_FROM_LISTS : GATHER_PLAIN;
+  const GatherMode from = (ctx->nbrValid && !ctx->nbrRows) ? GATHER_FROM_LISTS : GATHER_PLAIN;
   ctx->nbrValid = false;  // delta moves pStar: the lists are stale afterwards
   ctx->omegaValid = false;  // (and may write the buffer the last vorticity pass left its result in)
   int rc;
@@ -837,7 +947,9 @@ template <typename N> int stage_finalise(pbf_ctx *ctx, const pbf_params *p) {
     hipLaunchKernelGGL((k_finalise_predict<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c,
                        ctx->type[s].as<const uint8_t>(), ctx->pstar[s].as<vec4<N>>(), ctx->pos4[s].as<vec4<N>>(),
                        ctx->vel4[s].as<vec4<N>>(), ctx->wells.as<const N>(), ctx->key[s].as<uint32_t>(),
-                       ctx->count.as<uint32_t>());
+                       ctx->count.as<uint32_t>(), ctx->rowPstar[ctx->rcur].as<const vec4<N>>(),
+                       ctx->pstarInRows ? ctx->rowSlotOf.as<const uint32_t>() : nullptr);
+    ctx->pstarInRows = false, ctx->rowsValid = false, ctx->rowsCurrent = false;
     LAUNCH_CHECK(ctx);
     ctx->sorted = false, ctx->nbrValid = false, ctx->qposValid = false, ctx->omegaValid = false;
     ctx->counted = true, ctx->countedTableN = c.tableN;
@@ -845,10 +957,17 @@ template <typename N> int stage_finalise(pbf_ctx *ctx, const pbf_params *p) {
     return PBF_OK;
   }
   ctx->fuseNextPredict = false;
+  if (ctx->pstarInRows && (p->vorticity || p->xsph))  // the extras read the Morton-sorted pStar
+    if (int rc = materialise_pstar<N>(ctx)) return rc;
   StageTimer t(ctx, ST_FINALISE);
-  hipLaunchKernelGGL((k_finalise<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c,
-                     ctx->type[s].as<const uint8_t>(), ctx->pstar[ctx->pcur].as<const vec4<N>>(),
-                     ctx->pos4[s].as<vec4<N>>(), ctx->vel4[s].as<vec4<N>>());
+  if (ctx->pstarInRows)
+    hipLaunchKernelGGL((k_finalise<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, ctx->type[s].as<const uint8_t>(),
+                       ctx->rowPstar[ctx->rcur].as<const vec4<N>>(), ctx->pos4[s].as<vec4<N>>(), ctx->vel4[s].as<vec4<N>>(),
+                       ctx->rowSlotOf.as<const uint32_t>());
+  else
+    hipLaunchKernelGGL((k_finalise<N>), grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c, ctx->type[s].as<const uint8_t>(),
+                       ctx->pstar[ctx->pcur].as<const vec4<N>>(), ctx->pos4[s].as<vec4<N>>(), ctx->vel4[s].as<vec4<N>>(),
+                       static_cast<const uint32_t *>(nullptr));
   LAUNCH_CHECK(ctx);
   // keep pstar[cur] as the live buffer so that a later sort scatters pstar[cur] -> pstar[1-cur]
   if (ctx->pcur != s) {
@@ -983,6 +1102,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   else if (n == "fuse_predict") ctx->fusePredict = value != 0;
   else if (n == "timing_mask") ctx->timingMask = uint32_t(value);
   else if (n == "pad_lds") ctx->padLds = uint32_t(value);
+  else if (n == "row_major") ctx->rowMajor = int(value);
   else if (n == "nbr_chunks") {  // diagnostic: size of the lists' second tier (before the first upload; 0 = capacity / 16 + 1024)
     if (ctx->cap) return fail(ctx, PBF_ERR_STATE, "nbr_chunks must be set before the first upload");
     ctx->nbrChunksOpt = uint32_t(value);
@@ -1041,6 +1161,7 @@ int pbf_create(const pbf_desc *desc, pbf_ctx **out) {
   if (const char *e = std::getenv("PBF_LIST_MAX")) ctx->listMax = uint32_t(std::atoi(e));
   if (const char *e = std::getenv("PBF_OVERLAP_DIFFUSE")) ctx->overlapDiffuse = std::atoi(e) != 0, ctx->overlapDiffuseForced = true;
   if (const char *e = std::getenv("PBF_PIPELINE")) ctx->pipeline = std::atoi(e);
+  if (const char *e = std::getenv("PBF_ROW_MAJOR")) ctx->rowMajor = std::atoi(e);
   if (const char *e = std::getenv("PBF_GRAPH")) ctx->graphMode = std::atoi(e);
   if (const char *e = std::getenv("PBF_COOP")) {
     const int v = std::atoi(e);
@@ -1079,7 +1200,7 @@ void pbf_destroy(pbf_ctx *ctx) {
                    &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2], &ctx->count, &ctx->table,   &ctx->blockSums,
                    &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl, &ctx->bigCells,
                    &ctx->latticePN, &ctx->latticeC, &ctx->mcCounts, &ctx->mcOffsets, &ctx->mcSums, &ctx->mcNear, &ctx->meshV, &ctx->meshN,
-                   &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR, &ctx->colHist, &ctx->wireSend[0], &ctx->wireSend[1], &ctx->wireRecv[0], &ctx->wireRecv[1], &ctx->wireGhost[0], &ctx->wireGhost[1], &ctx->diffSum, &ctx->diffCnt};
+                   &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->rowPstar[0], &ctx->rowPstar[1], &ctx->rowMass, &ctx->rowQpos, &ctx->rowXYZ, &ctx->rowType, &ctx->rowSlotOf, &ctx->linCount, &ctx->linTable, &ctx->linSums, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR, &ctx->colHist, &ctx->wireSend[0], &ctx->wireSend[1], &ctx->wireRecv[0], &ctx->wireRecv[1], &ctx->wireGhost[0], &ctx->wireGhost[1], &ctx->diffSum, &ctx->diffCnt};
   for (DevBuf *b : all)
     if (b->p) (void)hipFree(b->p);
   for (auto &g : ctx->graphs)
@@ -1394,7 +1515,10 @@ int pbf_read_buffer(pbf_ctx *ctx, int which, void *host, size_t bytes) {
       if (!ctx->sorted) return fail(ctx, PBF_ERR_STATE, "table not built yet");
       src = ctx->table.p, avail = size_t(ctx->tableN) * 4;
       break;
-    case PBF_BUF_PSTAR: src = ctx->pstar[ctx->pcur].p, avail = ctx->n * v; break;
+    case PBF_BUF_PSTAR:
+      if (int rc = ctx->fp64 ? materialise_pstar<double>(ctx) : materialise_pstar<float>(ctx)) return rc;
+      src = ctx->pstar[ctx->pcur].p, avail = ctx->n * v;
+      break;
     case PBF_BUF_NBR_COUNT: src = ctx->nbrCount.p, avail = (ctx->ghostsPending ? ctx->nOwned : ctx->n) * 4; break;
     case PBF_BUF_OMEGA:
       if (!ctx->omegaValid) return fail(ctx, PBF_ERR_STATE, "no vorticity pass since the arrays last changed (pbf_params.vorticity)");
@@ -1569,12 +1693,16 @@ template <typename N> int slab_add_ghosts(pbf_ctx *ctx, const void *rL, uint32_t
 
 template <typename N> int slab_pack(pbf_ctx *ctx, void *sL, void *sR, const void *field = nullptr) {
   const uint32_t m = ctx->sentL + ctx->sentR;
-  const vec4<N> *src = field ? static_cast<const vec4<N> *>(field) : ctx->pstar[ctx->pcur].as<const vec4<N>>();
+  // {pStar, lambda}: from wherever it currently lives — the row-major copy while the iterations run on it
+  const bool rows = !field && ctx->pstarInRows && ctx->rowsCurrent;
+  if (!field && ctx->pstarInRows && !rows) return fail(ctx, PBF_ERR_STATE, "slab pack: no current pStar");
+  const vec4<N> *src = field ? static_cast<const vec4<N> *>(field)
+                             : rows ? ctx->rowPstar[ctx->rcur].as<const vec4<N>>() : ctx->pstar[ctx->pcur].as<const vec4<N>>();
   if (m)
     hipLaunchKernelGGL((k_pack_field<N>), grid_for(m), dim3(BLOCK), 0, ctx->stream, ctx->sentL, ctx->sentR,
                        ctx->ghostSrcL.as<const uint32_t>(), ctx->ghostSrcR.as<const uint32_t>(),
                        ctx->slotOf.as<const uint32_t>(), src,
-                       static_cast<vec4<N> *>(sL), static_cast<vec4<N> *>(sR));
+                       static_cast<vec4<N> *>(sL), static_cast<vec4<N> *>(sR), rows ? ctx->rowSlotOf.as<const uint32_t>() : nullptr);
   LAUNCH_CHECK(ctx);
   return PBF_OK;
 }
@@ -1584,11 +1712,14 @@ template <typename N> int slab_unpack(pbf_ctx *ctx, const void *rL, const void *
   StepConsts<N> c;
   if (!ctx->haveParams) return fail(ctx, PBF_ERR_STATE, "pbf_slab_unpack before any stage");
   if (int rc = make_consts<N>(ctx, &ctx->lastParams, c)) return rc;
+  const bool rows = !field && ctx->pstarInRows && ctx->rowsCurrent;
   if (m)
     hipLaunchKernelGGL((k_unpack_field<N>), grid_for(m), dim3(BLOCK), 0, ctx->stream, c, ctx->ghostAt, ctx->gotL, ctx->gotR,
                        static_cast<const vec4<N> *>(rL), static_cast<const vec4<N> *>(rR),
-                       ctx->slotOf.as<const uint32_t>(), field ? static_cast<vec4<N> *>(field) : ctx->pstar[ctx->pcur].as<vec4<N>>(),
-                       field ? nullptr : ctx->qpos.as<uint2>());
+                       ctx->slotOf.as<const uint32_t>(),
+                       field ? static_cast<vec4<N> *>(field) : rows ? ctx->rowPstar[ctx->rcur].as<vec4<N>>() : ctx->pstar[ctx->pcur].as<vec4<N>>(),
+                       field ? nullptr : rows ? ctx->rowQpos.as<uint2>() : ctx->qpos.as<uint2>(),
+                       rows ? ctx->rowSlotOf.as<const uint32_t>() : nullptr);
   LAUNCH_CHECK(ctx);
   return PBF_OK;
 }
@@ -2101,6 +2232,7 @@ template <typename N> int surface_impl(pbf_ctx *ctx, const pbf_params *p, const 
   // 27-cell neighbourhoods those nodes need — after refreshing the copies' colours (the owners diffused them during the
   // step), receives the one node plane its last cubes share with the right-hand neighbour, and emits its cubes'
   // triangles: the ranks' meshes, concatenated in rank order, ARE the single-device mesh's cube order (x-major).
+  if (int rc = materialise_pstar<N>(ctx)) return rc;  // (slab mode reads the copies' pStar)
   const bool slab = ctx->slabConfigured && ctx->comm && ctx->comm->nranks > 1;
   if (ctx->slabConfigured && !slab) return fail(ctx, PBF_ERR_STATE, "pbf_surface in slab mode needs pbf_slab_attach");
   if (slab && !ctx->ghostsPending) return fail(ctx, PBF_ERR_STATE, "pbf_surface in slab mode must follow pbf_slab_step directly");

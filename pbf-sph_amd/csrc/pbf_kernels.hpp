@@ -330,12 +330,60 @@ template <typename N> struct ParticleArrays {
   uint32_t *key;
 };
 
+// ------------------------------------------------------------------------------------------------
+// Row-major working set of the solver iterations (round 3, option "row_major").  The Morton order keeps a cell's 27
+// neighbours within a few cache lines of each other, but it scatters the three x cells of a (dy, dz) row: the walk has to
+// treat a row as two runs (pair + single, parity-dependent), pad the first to an even length and select, per load, which run
+// a slot belongs to — 15.6 VALU per candidate slot against the 5 of the distance test itself.  So the data the K iterations
+// work on ({pStar, lambda}, the quantised copy, mass, type) is ALSO laid out cell-row-major — cell (x, y, z) of the box at
+// linear index (z EY + y) EX + x, x fastest; inside a cell the Morton-sorted order, i.e. the reference's — where the three
+// x cells of a row are ONE contiguous run: one 16-byte table load per row, a walk with no selects and no padding, lists of
+// row slots, candidates gathered from the row copy.  Same candidates in the same order as the Morton walk => the same bits.
+// The row grid is the cube [0, P)^3, P = the power of two above the largest extent: every cell the reference's table knows
+// (Morton code < tableN) has its coordinates below P — including the ones beyond the extent proper, which the walk does
+// visit (a particle predicted through the floor sits in such a cell, and the floor's walkers find it there).  A cell of the
+// cube whose code is tableN - 1 or more is empty for every walker (sph.hpp:206-208) and stays empty here; the particles with
+// such keys — in no cell — sit behind the last cell and walk the Morton table themselves, translating what they find through
+// rowSlotOf (`ROW_FALLBACK`).  At the cube's faces x - 1 / x + 1 wrap to codes >= tableN in the reference: the run is clamped.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t ROW_FALLBACK = 1u << 30;  // rowXYZ flag: this walker takes the Morton table
+template <typename N> struct RowArrays {
+  vec4<N> *pstar;      // [slot] {pStar.xyz, lambda}: the live Jacobi buffer at the time of the sort
+  N *mass;             // [slot]
+  uint2 *qpos;         // [slot] quantised pStar
+  uint32_t *xyz;       // [slot] cell coordinates x | y << 10 | z << 20 (| ROW_FALLBACK)
+  uint8_t *type;       // [slot]
+  uint32_t *slotOf;    // [Morton-sorted index] -> slot
+  const uint32_t *lintab;  // [cell (z P + y) P + x] first slot of the cell; [P^3] = first slot behind the cells
+  uint32_t *tail;      // allocator of the slots behind the cells
+  uint32_t pshift;     // P = 1 << pshift
+};
+__host__ __device__ inline bool row_cell_of(uint32_t key, uint32_t tableN, uint32_t pshift, uint32_t *lin) {
+  const uint32_t x = compact10(key), y = compact10(key >> 1), z = compact10(key >> 2);
+  *lin = (((z << pshift) | y) << pshift) | x;
+  return key + 1u < tableN;  // (a key >= tableN - 1 is "in no cell" for its neighbours, sph.hpp:206-208; below it, x, y, z < P)
+}
+
+// per cell of the cube: its population, read off the Morton table (one lane per Morton code)
+// (over every code of the cube — a bijection onto its cells, so no memset: a cell the table does not know is written 0)
+__global__ __launch_bounds__(BLOCK) void k_lin_count(uint32_t tableN, uint32_t pshift, const uint32_t *__restrict__ table,
+                                                     uint32_t *__restrict__ linCount) {
+  const uint32_t code = blockIdx.x * BLOCK + threadIdx.x;
+  if (code >= (1u << (3u * pshift))) {
+    if (code == (1u << (3u * pshift))) linCount[code] = 0u, linCount[code + 1u] = 0u;  // scan sentinel, tail allocator
+    return;
+  }
+  uint32_t lin;
+  const bool known = row_cell_of(code, tableN, pshift, &lin);
+  linCount[lin] = known ? table[code + 1u] - table[code] : 0u;
+}
+
 template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_rank_move(StepConsts<N> c, uint32_t n, uint32_t tableN,
                                                      const uint32_t *__restrict__ permTmp,
                                                      const uint32_t *__restrict__ table, ParticleArrays<N> src,
                                                      ParticleArrays<N> dst, uint32_t *__restrict__ slotOf,
-                                                     uint2 *__restrict__ qpos) {
+                                                     uint2 *__restrict__ qpos, RowArrays<N> row) {
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint32_t s = permTmp[i];
@@ -357,17 +405,38 @@ __global__ __launch_bounds__(BLOCK) void k_rank_move(StepConsts<N> c, uint32_t n
     }
   }
   const uint32_t d = lo + rank;
-  dst.pos4[d] = src.pos4[s];
+  const vec4<N> p4 = src.pos4[s];
+  dst.pos4[d] = p4;
   dst.vel4[d] = src.vel4[s];
   dst.col4[d] = src.col4[s];
   const vec4<N> ps = src.pstar[s];
-  dst.pstar[d] = ps;
   bool usable;
-  qpos[d] = quantise_position<N>(c, ps, &usable);  // what the first list build of the step tests candidates on
+  const uint2 q = quantise_position<N>(c, ps, &usable);
+  if (!row.lintab) {  // (row-major iterations: {pStar, lambda} and its quantised copy live in the row arrays from here on)
+    dst.pstar[d] = ps;
+    qpos[d] = q;  // what the first list build of the step tests candidates on
+  }
   dst.id[d] = src.id[s];
-  dst.type[d] = src.type[s];
+  const uint8_t ty = src.type[s];
+  dst.type[d] = ty;
   dst.key[d] = k;
   if (slotOf) slotOf[s] = d;  // slab mode: where did pre-sort particle s go
+  if (row.lintab) {  // the iterations' row-major copy: cell-row-major, inside a cell the Morton-sorted (= reference) order
+    uint32_t lin, slot;
+    const uint32_t x = compact10(k), y = compact10(k >> 1), z = compact10(k >> 2);
+    uint32_t flags = 0;
+    if (row_cell_of(k, tableN, row.pshift, &lin)) {
+      slot = row.lintab[lin] + rank;
+      // (P = 1024 only: the reference's 10-bit wrap makes cell 1023 a neighbour of cell 0 — those walkers take the Morton table)
+      if (row.pshift == 10u && (x == 0u || y == 0u || z == 0u || x == 1023u || y == 1023u || z == 1023u)) flags = ROW_FALLBACK;
+    } else {
+      slot = row.lintab[1u << (3u * row.pshift)] + atomicAdd(row.tail, 1u);  // (nobody finds these through a row run: any order)
+      flags = ROW_FALLBACK;
+    }
+    row.pstar[slot] = ps, row.mass[slot] = p4.w, row.qpos[slot] = q, row.type[slot] = ty;
+    row.xyz[slot] = x | (y << 10) | (z << 20) | flags;
+    row.slotOf[d] = slot;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -621,8 +690,9 @@ template <typename N, bool FAST> struct LambdaOp {
   using Src = vec4<N>;
   struct Args {
     vec4<N> *pstar;
-    const vec4<N> *pos4;
+    const vec4<N> *pos4;  // (mass = pos4[i].w) — or, pos4 == NULL, the row-major copy's plain mass array:
     const uint8_t *type;
+    const N *mass = nullptr;
   };
   static constexpr bool kNeedsCandidateType = false;
   static constexpr bool kFilter = true;
@@ -646,7 +716,7 @@ template <typename N, bool FAST> struct LambdaOp {
       return false;
     }
     pa = a.pstar[i];
-    mass = a.pos4[i].w;
+    mass = a.pos4 ? a.pos4[i].w : a.mass[i];
     gx = gy = gz = rho = N(0);
     return true;
   }
@@ -1553,6 +1623,151 @@ __global__ __launch_bounds__(BLOCK) void k_build_lists_op(StepConsts<N> c, typen
   op.end(c, args, i);
 }
 
+// ---- the row-major iteration kernels (RowArrays above) ---------------------------------------------------------------
+struct RowWalk {
+  const uint32_t *lintab, *xyz, *slotOf, *mtable;
+  uint32_t tableN, pshift;
+};
+// the run of row r (0..8: dy = r % 3 - 1, dz = r / 3 - 1) of the walker in cell (x, y, z): the cells x - 1 .. x + 1 of that
+// row, clamped at the cube's faces; a row outside the cube is empty
+struct RowRun {
+  uint32_t s, e;
+};
+__device__ inline RowRun row_run(const RowWalk &w, uint32_t x, uint32_t y, uint32_t z, uint32_t r) {
+  const uint32_t P = 1u << w.pshift, yy = y + r % 3u - 1u, zz = z + r / 3u - 1u;
+  RowRun run{0u, 0u};
+  if (yy < P && zz < P) {  // (unsigned: -1 wraps far beyond P)
+    const uint32_t base = ((zz << w.pshift) | yy) << w.pshift;
+    run.s = w.lintab[base + (x ? x - 1u : 0u)];
+    run.e = w.lintab[base + min(x + 2u, P)];  // (base + P = the next row's first cell = this row's end)
+  }
+  return run;
+}
+// every candidate of row-slot i in the reference's order, as a row slot: the serial form (walkers that take the Morton
+// table, rows that overflowed)
+template <typename F> __device__ inline void row_for_each_candidate(const RowWalk &w, uint32_t i, F &&f) {
+  const uint32_t c = w.xyz[i];
+  const uint32_t x = c & 1023u, y = (c >> 10) & 1023u, z = (c >> 20) & 1023u;
+  if (c & ROW_FALLBACK) {
+    for_each_candidate(morton_encode(x, y, z), w.mtable, w.tableN, [&](uint32_t b) { f(w.slotOf[b]); });
+    return;
+  }
+#pragma unroll 1
+  for (uint32_t r = 0; r < 9; ++r) {
+    const RowRun run = row_run(w, x, y, z, r);
+    for (uint32_t b = run.s; b < run.e; ++b) f(b);
+  }
+}
+
+// The list build with an op riding on it, on the row-major copy: lane = row slot.  A (dy, dz) row of three x cells is ONE
+// run [lintab[c - 1], lintab[c + 2]) — walked in pairs (one 16-byte load = two quantised candidates) from a per-lane byte
+// offset that advances by a constant per trip: no run select, no padding slot, one limit compare per slot.
+template <typename N, typename Op, int W, int LMAX = 32, int FW = 4>
+__global__ __launch_bounds__(BLOCK) void k_build_rows_op(StepConsts<N> c, typename Op::Args args, const uint2 *__restrict__ qpos,
+                                                         RowWalk rw, NbrLists lists) {
+  static_assert(4 * W + 2 <= QPOS_PAD, "qpos padding");
+  __shared__ uint32_t list[(LMAX + 2 * W) * BLOCK];  // per-lane staging: a trip appends up to 2 W past LMAX - 1
+  const uint32_t tid = threadIdx.x;
+  const uint32_t chunk = xcd_chunk();
+  const uint32_t i = chunk * BLOCK + tid;
+  if (i >= c.n) return;
+  Op op;
+  if (!op.begin(c, args, i)) {  // (obstacles, ghosts: the op has stored what it owes them)
+    lists.count[i] = 0;
+    return;
+  }
+  const char *qbase = reinterpret_cast<const char *>(qpos);
+  const uint2 qa = qpos[i];
+  // (the walker's own coordinates may be unusable — beyond +-2^22 units: it then takes everything; recomputed like the Morton build)
+  bool usable;
+  (void)quantise_position<N>(c, Op::load(args, i), &usable);
+  const qpair axy = __builtin_bit_cast(qpair, qa.x), azw = __builtin_bit_cast(qpair, qa.y);
+  const uint32_t t2 = usable ? QPOS_T * QPOS_T : 0xFFFFFFFFu;
+  auto within = [&](uint32_t qx, uint32_t qy) {
+    const qpair dxy = __builtin_bit_cast(qpair, qx) - axy, dzw = __builtin_bit_cast(qpair, qy) - azw;
+    return uint32_t(qdot2(__builtin_bit_cast(uint32_t, dzw), qdot2(__builtin_bit_cast(uint32_t, dxy)))) <= t2;
+  };
+  NbrWriter wr(lists, chunk, tid);
+  // the staging list's write cursor as an LDS BYTE offset (slot s of this lane at s * SLOT + tid * 4): appending is one
+  // store and "cursor += hit ? SLOT : 0" — a select and a full-rate add instead of select + add-with-carry + shift-or
+  constexpr uint32_t SLOT = BLOCK * 4u;
+  unsigned char *const lbase = reinterpret_cast<unsigned char *>(list) + tid * 4u;
+  auto staged = [&](uint32_t byteOff) -> uint32_t & { return *reinterpret_cast<uint32_t *>(lbase + byteOff); };
+  uint32_t written = 0, cur = 0;
+  auto flush = [&]() {
+    const uint32_t nl = cur / SLOT;
+    wr.reserve(lists, written, nl);
+    for (uint32_t q = 0; __any(q < nl); q += FW) {  // FW survivors per trip: their gathers and pair terms interleave
+      uint32_t b[FW];
+      typename Op::Src cnd[FW];
+#pragma unroll
+      for (uint32_t w = 0; w < FW; ++w) b[w] = q + w < nl ? staged((q + w) * SLOT) : i;
+#pragma unroll
+      for (uint32_t w = 0; w < FW; ++w) cnd[w] = Op::load(args, b[w]);
+#pragma unroll
+      for (uint32_t w = 0; w < FW; ++w) wr.put(written + q + w, b[w], q + w < nl);
+#pragma unroll
+      for (uint32_t w = 0; w < FW; ++w) op.add_bf(c, cnd[w], q + w < nl);
+    }
+    written += nl;
+    cur = 0;
+  };
+  const uint32_t cell = rw.xyz[i];
+  const bool slow = (cell & ROW_FALLBACK) != 0u;
+  if (__any(slow)) {
+    // the few walkers in no cell: the serial walk over the Morton table, every candidate tested
+    if (slow)
+      row_for_each_candidate(rw, i, [&](uint32_t b) {
+        const uint2 q = qpos[b];
+        if (within(q.x, q.y)) {
+          if (cur >= uint32_t(LMAX) * SLOT) {  // (lane-private drain: the others of the wave are not here)
+            const uint32_t nl = cur / SLOT;
+            wr.reserve(lists, written, nl);
+            for (uint32_t k = 0; k < nl; ++k) {
+              const uint32_t e = staged(k * SLOT);
+              wr.put(written + k, e, true);
+              op.add_bf(c, Op::load(args, e), true);
+            }
+            written += nl, cur = 0;
+          }
+          staged(cur) = b;
+          cur += SLOT;
+        }
+      });
+  }
+  const uint32_t x = cell & 1023u, y = (cell >> 10) & 1023u, z = (cell >> 20) & 1023u;
+  auto load_run = [&](uint32_t r) { return slow ? RowRun{0u, 0u} : row_run(rw, x, y, z, r); };
+  RowRun next = load_run(0);
+#pragma unroll
+  for (uint32_t r = 0; r < 9; ++r) {
+    const RowRun run = next;
+    if (r < 8) next = load_run(r + 1);
+    const uint32_t L = run.e - run.s;
+    uint32_t off = run.s * 8u, b0 = run.s;  // byte offset of / row slot at the trip's first candidate
+    for (uint32_t t = 0; __any(t < L); t += 2 * W) {
+      if (t < L) {
+        QPair cnd[W];
+#pragma unroll
+        for (uint32_t w = 0; w < W; ++w) cnd[w] = *reinterpret_cast<const QPair *>(qbase + off + 16u * w);  // (slots past L: padding / the next run, masked)
+#pragma unroll
+        for (uint32_t w = 0; w < W; ++w) {
+          const bool hit0 = (t + 2 * w < L) & within(cnd[w].ax, cnd[w].ay);
+          staged(cur) = b0 + 2 * w;  // branch-free append: the slot is kept only on a hit
+          cur += hit0 ? SLOT : 0u;
+          const bool hit1 = (t + 2 * w + 1 < L) & within(cnd[w].bx, cnd[w].by);
+          staged(cur) = b0 + 2 * w + 1u;
+          cur += hit1 ? SLOT : 0u;
+        }
+      }
+      off += 16u * W, b0 += 2 * W;
+      if (__any(cur >= uint32_t(LMAX) * SLOT)) flush();
+    }
+  }
+  flush();
+  lists.count[i] = wr.finish(written);
+  op.end(c, args, i);
+}
+
 // Pins a just-loaded candidate into registers at this point of the program.  Without it LLVM folds the loop-carried
 // phi(load in the prologue, load in the loop) back into ONE load at the loop head (InstCombine's phi-of-loads), which
 // silently un-pipelines k_gather_from_lists: the pair terms would again wait for gathers issued in the same trip.
@@ -1571,11 +1786,11 @@ template <typename N> __device__ inline void pin_registers(PosVel<N> &b) {
 // latencies (list entry -> candidate) instead of leaning on the other waves of its SIMD.  Slots past the row (the
 // prefetch runs up to 3 W - 1 ahead) are clamped to the row's last slot and their entries discarded, never used as
 // an address.  Same candidates in the same order: bit-identical to the serial form.
-template <typename N, typename Op, bool PIPELINED = true>
+template <typename N, typename Op, bool PIPELINED = true, bool ROWS = false>
 __global__ __launch_bounds__(BLOCK) void k_gather_from_lists(StepConsts<N> c, typename Op::Args args,
                                                              const uint32_t *__restrict__ key,
                                                              const uint32_t *__restrict__ table,
-                                                             NbrLists lists) {
+                                                             NbrLists lists, RowWalk rw = {}) {
   const uint32_t tid = threadIdx.x;
   const uint32_t chunk = xcd_chunk();
   const uint32_t i = chunk * BLOCK + tid;
@@ -1585,7 +1800,8 @@ __global__ __launch_bounds__(BLOCK) void k_gather_from_lists(StepConsts<N> c, ty
   const NbrReader rd(lists, i);
   const uint32_t cnt = rd.cnt;
   if (cnt == NBR_OVERFLOW) {
-    for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { op.add(c, Op::load(args, b)); });
+    if constexpr (ROWS) row_for_each_candidate(rw, i, [&](uint32_t b) { op.add(c, Op::load(args, b)); });
+    else for_each_candidate(key[i], table, c.tableN, [&](uint32_t b) { op.add(c, Op::load(args, b)); });
   } else if constexpr (PIPELINED) {
     constexpr uint32_t W = sizeof(N) == 4 ? 4 : 2;
     auto entry = [&](uint32_t slot) { return rd.entry(slot); };
@@ -1696,15 +1912,16 @@ template <typename N> __device__ inline void finalise_one(const StepConsts<N> &c
   v.x = (dxx * invdt + v.x) * N(VD), v.y = (dyy * invdt + v.y) * N(VD), v.z = (dzz * invdt + v.z) * N(VD);
 }
 
+// (rowSlotOf != NULL: pstar is the iterations' row-major copy, particle a's record sits at rowSlotOf[a])
 template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_finalise(StepConsts<N> c, const uint8_t *__restrict__ type,
                                                     const vec4<N> *__restrict__ pstar, vec4<N> *__restrict__ pos4,
-                                                    vec4<N> *__restrict__ vel4) {
+                                                    vec4<N> *__restrict__ vel4, const uint32_t *__restrict__ rowSlotOf) {
   const uint32_t a = blockIdx.x * BLOCK + threadIdx.x;
   if (a >= c.n) return;
   if (c.hasObstacles && type[a] != 0) return;  // obstacles and ghosts do not move here
   vec4<N> p = pos4[a], v = vel4[a];
-  finalise_one<N>(c, pstar[a], p, v);
+  finalise_one<N>(c, pstar[rowSlotOf ? rowSlotOf[a] : a], p, v);
   pos4[a] = p;
   vel4[a] = v;
 }
@@ -1717,7 +1934,9 @@ template <typename N>
 __global__ __launch_bounds__(BLOCK) void k_finalise_predict(StepConsts<N> c, const uint8_t *__restrict__ type,
                                                             vec4<N> *__restrict__ pstar, vec4<N> *__restrict__ pos4,
                                                             vec4<N> *__restrict__ vel4, const N *__restrict__ wells,
-                                                            uint32_t *__restrict__ key, uint32_t *__restrict__ count) {
+                                                            uint32_t *__restrict__ key, uint32_t *__restrict__ count,
+                                                            const vec4<N> *__restrict__ rowPstar,
+                                                            const uint32_t *__restrict__ rowSlotOf) {
   const uint32_t a = blockIdx.x * BLOCK + threadIdx.x;
   if (a >= c.n) return;
   const uint8_t ty = c.hasObstacles ? type[a] : uint8_t(0);
@@ -1727,7 +1946,7 @@ __global__ __launch_bounds__(BLOCK) void k_finalise_predict(StepConsts<N> c, con
   }
   vec4<N> p = pos4[a], v = vel4[a];
   if (ty == 0) {
-    finalise_one<N>(c, pstar[a], p, v);
+    finalise_one<N>(c, rowSlotOf ? rowPstar[rowSlotOf[a]] : pstar[a], p, v);
     pos4[a] = p;
   }
   uint32_t k;
@@ -1737,6 +1956,14 @@ __global__ __launch_bounds__(BLOCK) void k_finalise_predict(StepConsts<N> c, con
   if (!slab_stays(c, k)) return;
   uint32_t before, rank;
   wave_bucket_atomic(min(k, c.tableN), [&](uint32_t b, uint32_t cnt) { return atomicAdd(&count[b], cnt); }, before, rank);
+}
+
+// the iterations' row-major {pStar, lambda} back into the Morton-sorted array (stage-level read-backs, the opt-in extras)
+template <typename N>
+__global__ __launch_bounds__(BLOCK) void k_rows_to_morton(uint32_t n, const vec4<N> *__restrict__ rowPstar,
+                                                          const uint32_t *__restrict__ rowSlotOf, vec4<N> *__restrict__ pstar) {
+  const uint32_t a = blockIdx.x * BLOCK + threadIdx.x;
+  if (a < n) pstar[a] = rowPstar[rowSlotOf[a]];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -253,10 +253,13 @@ __global__ __launch_bounds__(BLOCK) void k_pack_field(uint32_t nL, uint32_t nR, 
                                                       const uint32_t *__restrict__ srcR,
                                                       const uint32_t *__restrict__ slotOf,
                                                       const vec4<N> *__restrict__ pstar, vec4<N> *__restrict__ outL,
-                                                      vec4<N> *__restrict__ outR) {
+                                                      vec4<N> *__restrict__ outR, const uint32_t *__restrict__ rowSlotOf) {
+  // (rowSlotOf != NULL: `pstar` is the iterations' row-major copy, sorted particle d sits at rowSlotOf[d])
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
-  if (j < nL) outL[j] = pstar[slotOf[srcL[j]]];
-  else if (j < nL + nR) outR[j - nL] = pstar[slotOf[srcR[j - nL]]];
+  if (j >= nL + nR) return;
+  uint32_t d = slotOf[j < nL ? srcL[j] : srcR[j - nL]];
+  if (rowSlotOf) d = rowSlotOf[d];
+  (j < nL ? outL[j] : outR[j - nL]) = pstar[d];
 }
 
 // copies <- owners: the copies sit at pre-sort indices ghostAt + j in arrival order (left, then right)
@@ -265,11 +268,13 @@ __global__ __launch_bounds__(BLOCK) void k_unpack_field(StepConsts<N> c, uint32_
                                                         const vec4<N> *__restrict__ inL,
                                                         const vec4<N> *__restrict__ inR,
                                                         const uint32_t *__restrict__ slotOf,
-                                                        vec4<N> *__restrict__ pstar, uint2 *__restrict__ qpos) {
+                                                        vec4<N> *__restrict__ pstar, uint2 *__restrict__ qpos,
+                                                        const uint32_t *__restrict__ rowSlotOf) {
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
   if (j >= nL + nR) return;
   const vec4<N> v = j < nL ? inL[j] : inR[j - nL];
-  const uint32_t d = slotOf[ghostAt + j];
+  uint32_t d = slotOf[ghostAt + j];
+  if (rowSlotOf) d = rowSlotOf[d];  // (pstar / qpos are then the row-major copies)
   pstar[d] = v;
   if (qpos) {  // (NULL when the field is not pStar: the extras' velocity / vorticity refresh)
     bool usable;

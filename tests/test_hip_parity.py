@@ -39,7 +39,9 @@ def mk(pkg, oracle, scene, fp64, flags=0, device_pow=True, gather=None):
     """gather=None leaves the PRODUCT DEFAULT (filtered lists, split_build 8, cell_diffuse 1); a variant is
     only selected where a test names it."""
     s = pkg.Solver(h=0.1, fp64=fp64, flags=flags)
-    if gather is not None:
+    if gather == "morton":
+        s.set_option("row_major", 0)
+    elif gather is not None:
         s.set_option("gather", gather)
     s.upload(**scene)
     o = oracle.Oracle(fp64, device_pow=device_pow)
@@ -93,12 +95,14 @@ def assert_state_equal(g, w, what=""):
 SCENES = ["cubes8192", "dam8192"]
 
 
-@pytest.fixture(params=["default", "global", "tiles"])
+@pytest.fixture(params=["default", "morton", "global", "tiles"])
 def variant(request):
-    """The gather kernels must all be bit-identical to the oracle: None = the product default (1 = neighbour
-    lists: quantised build with lambda riding on it + list-driven delta-p, per-cell diffuse), 0 = per-particle global
-    walk, 3 = the iteration per brick out of LDS tiles (pbf_tiles.hpp)."""
-    return {"default": None, "global": 0, "tiles": 3}[request.param]
+    """The gather kernels must all be bit-identical to the oracle: None = the product default (neighbour lists: quantised
+    build with lambda riding on it + list-driven delta-p, on the ROW-MAJOR copy of the iterations' working set — option
+    row_major = 1, csrc/pbf_kernels.hpp RowArrays; per-cell diffuse), "morton" = the same kernels' Morton-order forms
+    (row_major = 0: what slabs with options, hipGraph replay and the other split_build values run), 0 = per-particle
+    global walk, 3 = the iteration per brick out of LDS tiles (pbf_tiles.hpp)."""
+    return {"default": None, "morton": "morton", "global": 0, "tiles": 3}[request.param]
 
 # ------------------------------------------------------------------------------------------ A
 
@@ -146,7 +150,7 @@ def test_every_stage_bit_exact(pkg, oracle, scene, fp64, variant):
 @pytest.mark.parametrize("scene", SCENES)
 def test_free_running_bit_exact(pkg, oracle, scene, fp64, variant):
     """12 frames without re-seeding: GPU state == oracle(device_pow) state, bit for bit."""
-    if variant is not None and (scene == "cubes8192" or (fp64 and variant == 0)):
+    if variant not in (None, "morton") and (scene == "cubes8192" or (fp64 and variant == 0)):
         pytest.skip("alternative gather kernels run the dam-break scene (the plain walk in fp32 only): suite time")
     sc, side = get_scene(pkg, scene, fp64)
     s, _ = mk(pkg, oracle, sc, fp64, gather=variant)
@@ -310,7 +314,9 @@ def test_moving_box_bit_exact(pkg, oracle, variant):
 def test_edge_cases_bit_exact(pkg, oracle, variant):
     p, q = params_pair(pkg, oracle)
     s = pkg.Solver(h=0.1)
-    if variant is not None:
+    if variant == "morton":
+        s.set_option("row_major", 0)
+    elif variant is not None:
         s.set_option("gather", variant)
     # empty: "Particles depleted" (ompsph.hpp:122-126) — a no-op, not an error
     z = dict(id=np.zeros(0, np.uint64), type=np.zeros(0, np.uint8), mass=np.zeros(0, np.float32),
