@@ -45,7 +45,9 @@ STAGE_BYTES_F32 = {"advect+zindex": 52, "sortz+gridtable": 132, "sph-diffuse": 3
 STAGE_BYTES_F64 = {"advect+zindex": 100, "sortz+gridtable": 256, "sph-diffuse": 64, "sph-lambda": 32,
                    "sph-delta": 56, "sph-finalise": 120}
 # the kernel (rocprofv3 name) behind each timing entry of the default configuration
-KERNEL_OF = {"sph-lambda/list-build": "k_build_lists_q", "sph-lambda": "k_build_lists_op", "sph-delta": "k_gather_from_lists<DeltaOp>",
+# (sph-lambda: the list build with lambda riding on it, on the row-major copy — the default since round 3; with option
+# row_major = 0 the same launch is k_build_lists_op)
+KERNEL_OF = {"sph-lambda/list-build": "k_build_lists_q", "sph-lambda": "k_build_rows_op", "sph-delta": "k_gather_from_lists<DeltaOp>",
              "sph-lambda/gather": "k_gather_from_lists<LambdaOp>",
              "sph-finalise": "k_finalise", "advect+zindex": "k_predict"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
@@ -413,7 +415,7 @@ def main():
         elif dom == "sph-lambda" and not any(k.startswith("sph-lambda/") and split[k][1] > 0 for k in split):
             # default configuration: ONE kernel builds the lists and computes lambda on the way (k_build_lists_op)
             dom_bytes = 4 * S + 8 + 4 + 4 + 4 * mean_list + 4 + S
-            dom_bytes_note = ("list build + lambda in one kernel: 16 (own pStar) + 8 (quantised positions, once) + 4 (key) + 4 (mass) "
+            dom_bytes_note = ("list build + lambda in one kernel: 16 (own pStar) + 8 (quantised positions, once) + 4 (cell) + 4 (mass) "
                               "in; 4 (list length) + 4*mean_list (lists) + 4 (lambda) out")
         elif dom == "sph-lambda/gather":
             dom_bytes = sb["sph-lambda"]
