@@ -36,6 +36,7 @@ cli)
   $B --scene dam-break --particles 1048576 --solver-iter 4 -n 100 -w 20 --no-surface --resident -o "" 2>&1 | grep "Particle-steps\|Frame-time mean" | sed 's/^/cli resident 1M: /'
   $B --scene dam-break --particles 1048576 --solver-iter 4 -n 100 -w 20 -o "" 2>&1 | grep "Particle-steps\|Frame-time mean\|Vertex" | sed 's/^/cli advance 1M +surface: /'
   $B -n 200 -w 200 -o "" 2>&1 | grep "Particle-steps\|Frame-time mean\|Vertex\|Particle count" | sed 's/^/cli stock: /'
-  $B --scene dam-break --particles 1048576 --solver-iter 4 -n 50 -w 20 --slabs 2 -o "" 2>&1 | grep "Particle-steps\|Frame-time mean" | sed 's/^/cli 1M 2 slabs one GPU: /'
+  $B --scene dam-break --particles 1048576 --solver-iter 4 -n 50 -w 20 --slabs 2 --no-surface -o "" 2>&1 | grep "Particle-steps\|Frame-time mean" | sed 's/^/cli 1M 2 slabs one GPU (host-staged exchange), no surface: /'
+  $B --scene dam-break --particles 1048576 --solver-iter 4 -n 50 -w 20 --slabs 2 -o "" 2>&1 | grep "Particle-steps\|Frame-time mean\|Vertex" | sed 's/^/cli 1M 2 slabs one GPU, surface across the slabs: /'
   ;;
 esac; done
