@@ -85,7 +85,11 @@ int pbf_abi_version(void);
  * delta-p, bit-exact, default; 2 / 4 / 8 = that many lanes share a particle's list and reduce the kernel sums with wave
  * shuffles: rounding-level differences), "cell_diffuse" (one colour walk per occupied cell, default 1), "fuse_diffuse",
  * "overlap_diffuse", "fuse_predict", "pipeline", "graph", "pad_lds", "timing_mask" (bit i = stage i of pbf_stage_times is
- * bracketed with events).  Unknown names return PBF_ERR_INVALID. */
+ * bracketed with events), "row_major" (DEFAULT 1: the solver iterations run on a cell-ROW-major copy of {pStar, lambda,
+ * quantised position, mass, type} — one contiguous run per (dy, dz) row of the 27-cell stencil, lists of row slots; 0 =
+ * everything in Morton order), "nbr_chunks" (size of the pool of 24-slot overflow chunks of the two-tier neighbour lists;
+ * 0 = sized from the particle count).  Every setting of these two is bit-identical.  Unknown names return
+ * PBF_ERR_INVALID. */
 int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value);
 
 /* ---- particle state (replaces the std::vector<Particle>& in/out argument, src/sph.hpp:124) */
@@ -188,9 +192,10 @@ int pbf_read_lattice(pbf_ctx *ctx, uint64_t sample[3], void *pn, void *c);
 /* ---- multi-GPU: slab decomposition along x (no reference counterpart: it is single-device) ------
  * One process per GPU.  Every rank uses the GLOBAL grid (same pbf_params bounds), owns the cell columns
  * [xlo, xhi) and keeps a one-cell layer of COPIES ("ghosts", type bit PBF_TYPE_GHOST) of its x-neighbours'
- * boundary columns.  The library selects / packs / appends / unpacks on the device; the caller moves the
- * wire buffers (device pointers) with RCCL — e.g. torch.distributed "nccl" send/recv over xGMI — see
- * pbf-sph_amd/slab.py for the per-step protocol:
+ * boundary columns.  The product path is pbf_slab_attach + pbf_slab_step further down: the whole step including the
+ * RCCL exchanges runs inside the library.  The calls of THIS section are the same step cut into its stages (select /
+ * pack / append / unpack on the device, the caller moves the wire buffers, which are device pointers) — kept so that
+ * tests can check every stage against the oracle and drive several ranks on one GPU; see pbf-sph_amd/slab.py:
  *   predict -> migrate -> add_migrants -> ghosts -> add_ghosts -> sort -> diffuse ->
  *   K x { lambda -> pack/exchange/unpack -> delta -> pack/exchange/unpack } -> finalise -> finish */
 enum { PBF_TYPE_GHOST = 2 };
