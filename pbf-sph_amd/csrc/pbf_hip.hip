@@ -130,6 +130,11 @@ struct pbf_ctx {
   // option "row_major": the iterations' working set also laid out cell-row-major (csrc/pbf_kernels.hpp RowArrays)
   int rowMajor = 1;           // default ON since round 3: -3 % per step at 1 M, -10 % at 4 M (profiles/r03_matrix.txt)
   DevBuf rowPstar[2], rowMass, rowQpos, rowXYZ, rowType, rowSlotOf, linCount, linTable, linSums;
+  DevBuf rowCol, rowMortonOf, rowSegs;  // k_diffuse_rows: the colours in row order, slot -> Morton index, non-empty segments
+  uint32_t rowSegShift = 0;
+  int rowDiffuse = 1;        // option "row_diffuse": the diffusion runs on the row-major copy (k_diffuse_rows)
+  bool bricksValid = false;  // ctx->bricks lists the non-empty bricks of the current table
+  bool rowColValid = false;  // rowCol holds the colours of col4[cur] (set by the sort, consumed by the diffusion)
   int rcur = 0;               // which rowPstar buffer is live
   bool rowsValid = false;     // the row arrays describe this step's sorted set (built by the sort)
   bool nbrRows = false;       // the current neighbour lists hold ROW slots (built by k_build_rows_op)
@@ -470,6 +475,17 @@ template <typename N> int stage_predict(pbf_ctx *ctx, const pbf_params *p) {
 
 bool row_mode(const pbf_ctx *ctx);
 
+// list of the non-empty 4 x 4 x 4 bricks for the persistent brick kernels (k_diffuse_bricks, pbf_tiles.hpp): built by the sort
+// stage when one of them is going to run, otherwise by whoever turns out to need it
+void brick_list(pbf_ctx *ctx, uint32_t tableN, bool counterIsZero = false) {
+  if (ctx->bricksValid) return;
+  if (!counterIsZero) (void)hipMemsetAsync(ctx->brickCtl.p, 0, 4, ctx->stream);
+  const uint32_t home = Brick<kBrickZ>::HOME, nBricks = (tableN + home - 1) / home;
+  hipLaunchKernelGGL(k_brick_list, grid_for(nBricks), dim3(BLOCK), 0, ctx->stream, ctx->table.as<const uint32_t>(), tableN, home,
+                     nBricks, ctx->bricks.as<uint32_t>(), ctx->brickCtl.as<uint32_t>());
+  ctx->bricksValid = true;
+}
+
 template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
   // the scatter consumes the histogram k_predict built (atomicSub back to zero): never run it twice
   if (!ctx->counted) return fail(ctx, PBF_ERR_STATE, "pbf_stage_sort needs pbf_stage_predict first");
@@ -488,7 +504,7 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
   // option "row_major": the box cells' populations in cell-row-major order and their scan (the row table), read off the
   // Morton table; k_rank_move below then writes the iterations' row-major copy on its way
   RowArrays<N> row{};
-  ctx->rowsValid = false, ctx->pstarInRows = false, ctx->rowsCurrent = false;
+  ctx->rowsValid = false, ctx->pstarInRows = false, ctx->rowsCurrent = false, ctx->rowColValid = false;
   if (row_mode(ctx)) {
     // the cube that holds every cell the Morton table knows: P = 2^(bits of tableN / 3, rounded up)
     uint32_t pshift = 1;
@@ -506,6 +522,14 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
     if (int rc = ensure(ctx, ctx->rowXYZ, ctx->cap * 4)) return rc;
     if (int rc = ensure(ctx, ctx->rowType, ctx->cap)) return rc;
     if (int rc = ensure(ctx, ctx->rowSlotOf, ctx->cap * 4)) return rc;
+    const bool rowDiffuse = ctx->cellDiffuse && ctx->rowDiffuse > 0;
+    const uint32_t segShift = std::min<uint32_t>(pshift, 6u);  // segments of 64 x cells (the whole row in a smaller cube)
+    const size_t nSegTotal = ncells >> segShift;
+    if (rowDiffuse) {
+      if (int rc = ensure(ctx, ctx->rowCol, ctx->cap * v)) return rc;
+      if (int rc = ensure(ctx, ctx->rowMortonOf, ctx->cap * 4)) return rc;
+      if (int rc = ensure(ctx, ctx->rowSegs, (std::min(nSegTotal, ctx->cap) + 1) * 4)) return rc;
+    }
     hipLaunchKernelGGL(k_lin_count, grid_for(ncells + 1), dim3(BLOCK), 0, ctx->stream, c.tableN, pshift, table,
                        ctx->linCount.as<uint32_t>());
     hipLaunchKernelGGL(k_scan_block_sums, dim3(lnb), dim3(BLOCK), 0, ctx->stream, ctx->linCount.as<const uint32_t>(), uint32_t(llen),
@@ -513,11 +537,16 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->linSums.as<uint32_t>(), lnb);
     hipLaunchKernelGGL(k_scan_apply, dim3(lnb), dim3(BLOCK), 0, ctx->stream, ctx->linCount.as<const uint32_t>(), uint32_t(llen),
                        ctx->linSums.as<const uint32_t>(), ctx->linTable.as<uint32_t>());
+    if (rowDiffuse)  // the x-segments that hold a particle (at most one per particle), for k_diffuse_rows
+      hipLaunchKernelGGL(k_row_segments, grid_for(nSegTotal), dim3(BLOCK), 0, ctx->stream, pshift, segShift,
+                         ctx->linTable.as<const uint32_t>(), ctx->rowSegs.as<uint32_t>(), ctx->linCount.as<uint32_t>() + ncells + 2);
     ctx->rcur = 0;
     row = RowArrays<N>{ctx->rowPstar[0].as<vec4<N>>(), ctx->rowMass.as<N>(), ctx->rowQpos.as<uint2>(), ctx->rowXYZ.as<uint32_t>(),
-                       ctx->rowType.as<uint8_t>(), ctx->rowSlotOf.as<uint32_t>(), ctx->linTable.as<const uint32_t>(),
-                       ctx->linCount.as<uint32_t>() + ncells + 1, pshift};
-    ctx->rowShift = pshift;
+                       ctx->rowType.as<uint8_t>(), ctx->rowSlotOf.as<uint32_t>(),
+                       rowDiffuse ? ctx->rowCol.as<vec4<N>>() : nullptr, rowDiffuse ? ctx->rowMortonOf.as<uint32_t>() : nullptr,
+                       ctx->linTable.as<const uint32_t>(), ctx->linCount.as<uint32_t>() + ncells + 1, pshift};
+    ctx->rowShift = pshift, ctx->rowSegShift = segShift;
+    ctx->rowColValid = rowDiffuse;
     ctx->rowsValid = true, ctx->rowsCurrent = true;
   }
   // brickCtl = {nActive bricks, tickets[kTickets], number of big cells}: zeroed once per step
@@ -538,12 +567,9 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
                      ctx->permTmp.as<const uint32_t>(), table, arrays<N>(ctx, s, s), arrays<N>(ctx, d, d),
                      ctx->slabActive ? ctx->slotOf.as<uint32_t>() : nullptr, ctx->qpos.as<uint2>(), row);
   ctx->n = nLive;
-  {  // list of non-empty bricks for the persistent gather kernels (+ fresh tickets)
-    const uint32_t home = Brick<kBrickZ>::HOME, nBricks = (c.tableN + home - 1) / home;
-    hipLaunchKernelGGL(k_brick_list, grid_for(nBricks), dim3(BLOCK), 0, ctx->stream, table, c.tableN, home, nBricks,
-                       ctx->bricks.as<uint32_t>(), ctx->brickCtl.as<uint32_t>());
-    ctx->gatherSeq = 0;
-  }
+  ctx->gatherSeq = 0;  // (fresh tickets)
+  ctx->bricksValid = false;
+  if (!ctx->rowColValid) brick_list(ctx, c.tableN, /*counterIsZero=*/true);  // (the row-major diffusion has its own segments)
   LAUNCH_CHECK(ctx);
   ctx->cur = d;
   ctx->pcur = d;
@@ -618,6 +644,7 @@ int launch_gather(pbf_ctx *ctx, const StepConsts<N> &c, typename Op::Args args, 
     if (ctx->gatherKind == 3 && mode != GATHER_PLAIN && uint64_t(ctx->n) * sizeof(typename Op::Src) <= 0xFFFFFFFFull) {
       using B = TileBrick;
       static_assert(kBrickZ == TILE_BZ, "the sort stage's brick list is the tile kernels' one");
+      brick_list(ctx, c.tableN);
       constexpr int WAYS = 4, LMAX = 16;
       uint32_t cap = ctx->tileCap ? std::min(ctx->tileCap, 65535u) : 2048u;  // list entries of a tiled brick are tile slots
       uint32_t *nl = ctx->nbrList.as<uint32_t>(), *nc = ctx->nbrCount.as<uint32_t>();
@@ -745,7 +772,28 @@ template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p, bool 
             (ctx->overlapDiffuseForced || ctx->n >= (size_t(1) << 19));
   ctx->omegaValid = false;  // (the per-cell sums may be parked in pStar's idle Jacobi partner)
   StageTimer t(ctx, ST_DIFFUSE);
-  if (ctx->cellDiffuse && !(ctx->desc.flags & PBF_FLAG_NO_LDS)) {
+  if (ctx->cellDiffuse && ctx->rowColValid && ctx->rowsValid && ctx->rowDiffuse) {
+    // the row-major copy: one wave per segment of 64 x cells, runs staged through LDS, sums applied in place (k_diffuse_rows).
+    // On the solver's own stream: the launch is short, nothing is gained by hiding it
+    const uint32_t ncells = 1u << (3u * ctx->rowShift);
+    static const uint32_t capEnv = std::getenv("PBF_DIFF_CAP") ? uint32_t(std::atoi(std::getenv("PBF_DIFF_CAP"))) : 0u;  // (experiments)
+    const uint32_t cap = capEnv ? capEnv : 768u;  // records of one row's run (66 cells): the settled dam-break's are ~460 to 600; a longer one walks from memory
+    const size_t lds = size_t(cap) * sizeof(vec4<N>) + size_t(DIFFUSE_ROW_THREADS) * (4 * sizeof(N) + 4) + cap;
+    static size_t attrSet = 0;  // per instantiation
+    if (lds > attrSet) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_diffuse_rows<N>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+      attrSet = lds;
+    }
+    const uint32_t perCU = uint32_t(std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 256))));
+    const uint32_t blocks = std::max(8u, (uint32_t(ctx->numCUs) * perCU) & ~7u);  // (the kernel deals segments per XCD: a multiple of 8)
+    hipLaunchKernelGGL((k_diffuse_rows<N>), dim3(blocks), dim3(DIFFUSE_ROW_THREADS), lds, ctx->stream, c,
+                       row_walk<N>(ctx), ctx->rowCol.as<const vec4<N>>(), ctx->rowType.as<const uint8_t>(),
+                       ctx->rowMortonOf.as<const uint32_t>(), ctx->rowSegs.as<const uint32_t>(),
+                       ctx->linCount.as<const uint32_t>() + ncells + 2, ctx->rowSegShift, args.colOut, cap, uint32_t(ctx->n));
+    LAUNCH_CHECK(ctx);
+    ctx->rowColValid = false;  // (col4 moves on: the copy is the pre-diffusion state)
+  } else if (ctx->cellDiffuse && !(ctx->desc.flags & PBF_FLAG_NO_LDS)) {
+    brick_list(ctx, c.tableN);
     // sums per cell, parked in buffers that are idle here (the Jacobi partner of pStar and the list lengths) — or, when
     // the stage runs beside the solver iterations, in scratch of its own
     vec4<N> *cellSum = ctx->pstar[other_pstar(ctx)].as<vec4<N>>();
@@ -1103,6 +1151,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   else if (n == "timing_mask") ctx->timingMask = uint32_t(value);
   else if (n == "pad_lds") ctx->padLds = uint32_t(value);
   else if (n == "row_major") ctx->rowMajor = int(value);
+  else if (n == "row_diffuse") ctx->rowDiffuse = int(value);
   else if (n == "nbr_chunks") {  // diagnostic: size of the lists' second tier (before the first upload; 0 = capacity / 16 + 1024)
     if (ctx->cap) return fail(ctx, PBF_ERR_STATE, "nbr_chunks must be set before the first upload");
     ctx->nbrChunksOpt = uint32_t(value);
@@ -1200,7 +1249,7 @@ void pbf_destroy(pbf_ctx *ctx) {
                    &ctx->pstar[0], &ctx->pstar[1], &ctx->pstar[2], &ctx->count, &ctx->table,   &ctx->blockSums,
                    &ctx->permTmp, &ctx->wells,   &ctx->staging, &ctx->bricks, &ctx->brickCtl, &ctx->bigCells,
                    &ctx->latticePN, &ctx->latticeC, &ctx->mcCounts, &ctx->mcOffsets, &ctx->mcSums, &ctx->mcNear, &ctx->meshV, &ctx->meshN,
-                   &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->rowPstar[0], &ctx->rowPstar[1], &ctx->rowMass, &ctx->rowQpos, &ctx->rowXYZ, &ctx->rowType, &ctx->rowSlotOf, &ctx->linCount, &ctx->linTable, &ctx->linSums, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR, &ctx->colHist, &ctx->wireSend[0], &ctx->wireSend[1], &ctx->wireRecv[0], &ctx->wireRecv[1], &ctx->wireGhost[0], &ctx->wireGhost[1], &ctx->diffSum, &ctx->diffCnt};
+                   &ctx->meshC, &ctx->qpos, &ctx->nbrList, &ctx->nbrCount, &ctx->rowPstar[0], &ctx->rowPstar[1], &ctx->rowMass, &ctx->rowQpos, &ctx->rowXYZ, &ctx->rowType, &ctx->rowSlotOf, &ctx->rowCol, &ctx->rowMortonOf, &ctx->rowSegs, &ctx->linCount, &ctx->linTable, &ctx->linSums, &ctx->slotOf,  &ctx->selCounts, &ctx->selTotals, &ctx->ghostSrcL, &ctx->ghostSrcR, &ctx->colHist, &ctx->wireSend[0], &ctx->wireSend[1], &ctx->wireRecv[0], &ctx->wireRecv[1], &ctx->wireGhost[0], &ctx->wireGhost[1], &ctx->diffSum, &ctx->diffCnt};
   for (DevBuf *b : all)
     if (b->p) (void)hipFree(b->p);
   for (auto &g : ctx->graphs)

@@ -354,6 +354,8 @@ template <typename N> struct RowArrays {
   uint32_t *xyz;       // [slot] cell coordinates x | y << 10 | z << 20 (| ROW_FALLBACK)
   uint8_t *type;       // [slot]
   uint32_t *slotOf;    // [Morton-sorted index] -> slot
+  vec4<N> *col;        // [slot] colour before the step's diffusion (k_diffuse_rows reads its runs from here); may be NULL
+  uint32_t *mortonOf;  // [slot] -> Morton-sorted index (with col)
   const uint32_t *lintab;  // [cell (z P + y) P + x] first slot of the cell; [P^3] = first slot behind the cells
   uint32_t *tail;      // allocator of the slots behind the cells
   uint32_t pshift;     // P = 1 << pshift
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void k_lin_count(uint32_t tableN, uint32_t p
                                                      uint32_t *__restrict__ linCount) {
   const uint32_t code = blockIdx.x * BLOCK + threadIdx.x;
   if (code >= (1u << (3u * pshift))) {
-    if (code == (1u << (3u * pshift))) linCount[code] = 0u, linCount[code + 1u] = 0u;  // scan sentinel, tail allocator
+    if (code == (1u << (3u * pshift))) linCount[code] = 0u, linCount[code + 1u] = 0u, linCount[code + 2u] = 0u;  // scan sentinel, tail allocator, segment counter
     return;
   }
   uint32_t lin;
@@ -408,7 +410,8 @@ __global__ __launch_bounds__(BLOCK) void k_rank_move(StepConsts<N> c, uint32_t n
   const vec4<N> p4 = src.pos4[s];
   dst.pos4[d] = p4;
   dst.vel4[d] = src.vel4[s];
-  dst.col4[d] = src.col4[s];
+  const vec4<N> cl = src.col4[s];
+  dst.col4[d] = cl;
   const vec4<N> ps = src.pstar[s];
   bool usable;
   const uint2 q = quantise_position<N>(c, ps, &usable);
@@ -436,6 +439,7 @@ __global__ __launch_bounds__(BLOCK) void k_rank_move(StepConsts<N> c, uint32_t n
     row.pstar[slot] = ps, row.mass[slot] = p4.w, row.qpos[slot] = q, row.type[slot] = ty;
     row.xyz[slot] = x | (y << 10) | (z << 20) | flags;
     row.slotOf[d] = slot;
+    if (row.col) row.col[slot] = cl, row.mortonOf[slot] = d;
   }
 }
 
@@ -1656,6 +1660,172 @@ template <typename F> __device__ inline void row_for_each_candidate(const RowWal
   for (uint32_t r = 0; r < 9; ++r) {
     const RowRun run = row_run(w, x, y, z, r);
     for (uint32_t b = run.s; b < run.e; ++b) f(b);
+  }
+}
+
+// ---- diffusion on the row-major copy ------------------------------------------------------------------------------------
+// Diffuse has no distance test, so every particle of a cell folds the very same candidates in the very same order (see
+// k_diffuse_bricks): one lane per CELL does the walk.  In the row-major copy a wave takes a SEGMENT of up to 64 consecutive
+// x cells of one (y, z) row: for each of the nine (dy, dz) rows, the candidates of all its cells are ONE contiguous run of
+// the colour copy — cells x0 - 1 .. x0 + 64 — which the wave copies into LDS with fully coalesced loads (a few records per
+// lane) and each lane then folds its own three-cell sub-run out of it, in the reference's order.  The wave finally applies the
+// sums to the segment's own particles (again a contiguous run) and writes the new colours to their Morton-sorted places:
+// no per-cell sums in memory, no second pass, no halo gather.  k_row_segments lists the segments that hold a particle
+// (persistent workgroups stride over that list).  Cells whose walkers take the Morton table (P = 1024 faces) and the
+// particles in no cell walk serially, as they do in the iteration kernels.
+constexpr int DIFFUSE_ROW_THREADS = 64;
+// LDS-DMA (global_load_lds_dwordx4): every active lane's 16 bytes at `src` (per lane) land at `ldsBase` (wave-uniform) + 16 x
+// lane — no VGPR destination; completion is counted on vmcnt
+__device__ inline void lds_dma16(const void *src, void *ldsBase) {
+  using G = const __attribute__((address_space(1))) void *;
+  using L = __attribute__((address_space(3))) void *;
+  __builtin_amdgcn_global_load_lds((G)(uintptr_t)src, (L)(uint32_t)(uintptr_t)ldsBase, 16, 0, 0);
+}
+__global__ __launch_bounds__(BLOCK) void k_row_segments(uint32_t pshift, uint32_t segShift, const uint32_t *__restrict__ lintab,
+                                                        uint32_t *__restrict__ segs, uint32_t *__restrict__ nSegs) {
+  const uint32_t sg = blockIdx.x * BLOCK + threadIdx.x;
+  if (sg >= (1u << (3u * pshift - segShift))) return;
+  const uint32_t c0 = sg << segShift;
+  if (lintab[c0 + (1u << segShift)] != lintab[c0]) segs[atomicAdd(nSegs, 1u)] = sg;  // (any order: segments are independent)
+}
+
+template <typename N>
+__global__ __launch_bounds__(DIFFUSE_ROW_THREADS) void k_diffuse_rows(StepConsts<N> c, RowWalk rw, const vec4<N> *__restrict__ rowCol,
+                                                                      const uint8_t *__restrict__ rowType,
+                                                                      const uint32_t *__restrict__ mortonOf,
+                                                                      const uint32_t *__restrict__ segs,
+                                                                      const uint32_t *__restrict__ nSegsPtr, uint32_t segShift,
+                                                                      vec4<N> *__restrict__ colOut, uint32_t cap, uint32_t nSlots) {
+  constexpr uint32_t T = DIFFUSE_ROW_THREADS;
+  constexpr uint32_t UNITS = sizeof(vec4<N>) / 16u;  // 16-byte pieces per record (what one lane of an LDS-DMA moves)
+  extern __shared__ __align__(16) unsigned char smem[];
+  vec4<N> *tile = reinterpret_cast<vec4<N> *>(smem);                     // [cap] one row's run of colours
+  N *sums = reinterpret_cast<N *>(smem + size_t(cap) * sizeof(vec4<N>));  // [4][T] the cells' sums for the apply pass
+  uint32_t *cnts = reinterpret_cast<uint32_t *>(sums + 4 * T);            // [T]
+  uint8_t *flag = reinterpret_cast<uint8_t *>(cnts + T);                  // [cap] candidate types (only with obstacles)
+  const uint32_t lane = threadIdx.x, P = 1u << rw.pshift, X = 1u << segShift;
+  const uint32_t *__restrict__ lintab = rw.lintab;
+  const uint32_t nSegs = *nSegsPtr;
+  typename DiffuseOp<N>::Args out{nullptr, colOut, nullptr};
+  const bool typed = c.hasObstacles != 0u;
+  // workgroup -> segment: each XCD (workgroups are dealt to the 8 XCDs round robin) takes a contiguous eighth of the list,
+  // so the rows a segment shares with its y / z neighbours are found in that XCD's L2
+  const uint32_t xcd = blockIdx.x & 7u, perXcd = gridDim.x >> 3, segsPerXcd = (nSegs + 7u) >> 3;
+  const uint32_t tEnd = min(nSegs, (xcd + 1u) * segsPerXcd);
+  for (uint32_t t = xcd * segsPerXcd + (blockIdx.x >> 3); t < tEnd; t += perXcd) {
+    const uint32_t c0 = segs[t] << segShift;
+    const uint32_t x0 = c0 & (P - 1u), y = (c0 >> rw.pshift) & (P - 1u), z = c0 >> (2u * rw.pshift);
+    const uint32_t x = x0 + lane;
+    uint32_t ownS = 0, ownE = 0;
+    if (lane < X) ownS = lintab[c0 + lane], ownE = lintab[c0 + lane + 1u];
+    const bool live = ownE > ownS;
+    // (a per-cell property, P = 1024 only: the walkers of the cube's face cells take the Morton table)
+    const bool serial = rw.pshift == 10u && live && (rw.xyz[ownS] & ROW_FALLBACK) != 0u;
+    N mx = N(0), my = N(0), mz = N(0), mw = N(0);
+    uint32_t nn = 0;
+    auto add = [&](const vec4<N> &cb) { mx += cb.x, my += cb.y, mz += cb.z, mw += cb.w, ++nn; };
+    // the segment's own particles [hs, he), lane l takes hs + l, hs + l + 64, ...: what the apply pass at the end needs of the
+    // first OWN x 64 of them is requested now and arrives while the planes are folded
+    constexpr uint32_t OWN = 8;
+    const uint32_t hs = __shfl(ownS, 0), he = __shfl(ownE, int(X) - 1);
+    vec4<N> ownCol[OWN];
+    uint32_t ownDst[OWN], ownXyz[OWN];
+    uint8_t ownTy[OWN];
+#pragma unroll
+    for (uint32_t k = 0; k < OWN; ++k) {
+      const uint32_t j = min(hs + lane + k * T, nSlots - 1u);
+      ownCol[k] = rowCol[j], ownDst[k] = mortonOf[j], ownXyz[k] = rw.xyz[j];
+      ownTy[k] = typed ? rowType[j] : uint8_t(0);
+    }
+    if (__any(serial)) {
+      if (serial)
+        for_each_candidate(morton_encode(x, y, z), rw.mtable, rw.tableN, [&](uint32_t b) {
+          const uint32_t sl = rw.slotOf[b];
+          if (!(typed && (rowType[sl] & 1))) add(rowCol[sl]);
+        });
+    }
+    // every table entry of the nine rows first (one round trip): the segment's run [rs, rs + len) and this lane's sub-run
+    uint32_t rs[9], len[9], ls[9], le[9];
+#pragma unroll
+    for (uint32_t r = 0; r < 9; ++r) {
+      const uint32_t yy = y + r % 3u - 1u, zz = z + r / 3u - 1u;
+      rs[r] = len[r] = ls[r] = le[r] = 0u;
+      if (yy < P && zz < P) {  // (uniform; unsigned: -1 wraps far beyond P) a row outside the cube is empty
+        const uint32_t base = ((zz << rw.pshift) | yy) << rw.pshift;
+        rs[r] = lintab[base + (x0 ? x0 - 1u : 0u)];
+        len[r] = lintab[base + min(x0 + X + 1u, P)] - rs[r];
+        if (live && !serial) ls[r] = lintab[base + (x ? x - 1u : 0u)], le[r] = lintab[base + min(x + 2u, P)];  // = row_run()
+      }
+    }
+    // one row per phase: its run goes to LDS by LDS-DMA — every piece in flight at once, no registers — and is folded once
+    // it has landed.  (A small tile: a dozen single-wave workgroups per CU hide each other's round trips; three rows per
+    // phase in a 32-KiB tile — 4 workgroups per CU, one wave per SIMD — measured 4 x slower: the walk is bound by the issue
+    // rate of ONE wave.)
+#pragma unroll
+    for (uint32_t r = 0; r < 9; ++r) {
+      if (len[r] == 0u) continue;  // (uniform)
+      if (len[r] <= cap) {
+        __syncthreads();  // the previous row's folds are done with the tile
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(rowCol + rs[r]);
+        unsigned char *dst = reinterpret_cast<unsigned char *>(tile);
+        const uint32_t units = len[r] * UNITS;
+        for (uint32_t u0 = 0; u0 < units; u0 += T)  // 1 KiB per wave-instruction: lane l's 16 bytes land at dst + 16 l
+          if (u0 + lane < units) lds_dma16(src + size_t(u0 + lane) * 16u, dst + size_t(u0) * 16u);
+        if (typed)
+          for (uint32_t k = lane; k < len[r]; k += T) flag[k] = rowType[rs[r] + k];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every piece has landed
+        __syncthreads();
+        const uint32_t s = ls[r] - rs[r], e = le[r] - rs[r];
+        if (typed) {
+          for (uint32_t j = s; j < e; ++j)
+            if (!(flag[j] & 1)) add(tile[j]);  // obstacles are skipped as candidates (ompsph.hpp:194)
+        } else {
+#pragma unroll 4
+          for (uint32_t j = s; j < e; ++j) {
+            const vec4<N> cb = tile[j];
+            mx += cb.x, my += cb.y, mz += cb.z, mw += cb.w;
+          }
+          nn += e - s;
+        }
+      } else {  // a run longer than the tile (a pile-up): straight from memory
+        for (uint32_t j = ls[r]; j < le[r]; ++j)
+          if (!(typed && (rowType[j] & 1))) add(rowCol[j]);
+      }
+    }
+    __syncthreads();
+    sums[lane] = mx, sums[T + lane] = my, sums[2 * T + lane] = mz, sums[3 * T + lane] = mw, cnts[lane] = nn;
+    __syncthreads();
+    auto apply = [&](const vec4<N> &ca, uint32_t dst, uint32_t xyz, uint8_t ty) {
+      if (typed && ty != 0) {  // obstacle, or a ghost copy owned by the neighbouring slab: unchanged
+        colOut[dst] = ca;
+        return;
+      }
+      DiffuseOp<N> op;
+      op.ca = ca;
+      const uint32_t cx = (xyz & 1023u) - x0;
+      op.mx = sums[cx], op.my = sums[T + cx], op.mz = sums[2 * T + cx], op.mw = sums[3 * T + cx], op.nn = int(cnts[cx]);
+      op.end(c, out, dst);
+    };
+#pragma unroll
+    for (uint32_t k = 0; k < OWN; ++k)
+      if (hs + lane + k * T < he) apply(ownCol[k], ownDst[k], ownXyz[k], ownTy[k]);
+    for (uint32_t j = hs + lane + OWN * T; j < he; j += T)  // (a segment of more than OWN x 64 particles)
+      apply(rowCol[j], mortonOf[j], rw.xyz[j], typed ? rowType[j] : uint8_t(0));
+  }
+  // the particles in no cell (behind the last cell): one lane each, the serial walk
+  for (uint32_t j = lintab[1u << (3u * rw.pshift)] + blockIdx.x * T + lane; j < nSlots; j += gridDim.x * T) {
+    DiffuseOp<N> op;
+    op.ca = rowCol[j];
+    op.mx = op.my = op.mz = op.mw = N(0), op.nn = 0;
+    const uint32_t dst = mortonOf[j];
+    if (typed && rowType[j] != 0) {
+      colOut[dst] = op.ca;
+      continue;
+    }
+    row_for_each_candidate(rw, j, [&](uint32_t b) {
+      if (!(typed && (rowType[b] & 1))) op.add(c, rowCol[b]);
+    });
+    op.end(c, out, dst);
   }
 }
 

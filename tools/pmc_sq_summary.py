@@ -62,9 +62,13 @@ if limiter_out:
         # the verdict a reader should take away: which unit is closest to saturation, and that none is saturated
         shares = {"valu pipe": e["valu_pipe_busy_frac"], "texture-address path": e.get("texture_address_busy_frac", 0.0)}
         top = max(shares, key=shares.get)
-        e["measured_limiter"] = (f"{top} {shares[top]:.0%} busy by instruction COUNT, waves waiting {e['wave_waiting_frac']:.0%} / "
-                                 f"ready-not-issued {e['wave_ready_not_issued_frac']:.0%} of their life: no unit saturated by count; "
-                                 "priced by instruction class (compares / selects / v_dot2 / v_pk_sub take 1.7 issue slots, "
-                                 "profiles/r02_valu_rates.md) the list build is ~75 % VALU-issue bound (DESIGN.md section 5)")
+        msg = (f"{top} {shares[top]:.0%} busy by instruction COUNT, waves waiting {e['wave_waiting_frac']:.0%} / "
+               f"ready-not-issued {e['wave_ready_not_issued_frac']:.0%} of their life: no unit saturated by count")
+        if "k_build" in k:
+            msg += ("; priced by instruction class (compares / selects / v_dot2 / v_pk_sub take 1.7 issue slots, "
+                    "profiles/r02_valu_rates.md) the list build is ~75 % VALU-issue bound (DESIGN.md section 5)")
+        elif e["wave_waiting_frac"] >= 0.6:
+            msg += "; latency bound (waves wait on memory / LDS most of their life)"
+        e["measured_limiter"] = msg
         rec[k] = e
     json.dump(rec, open(limiter_out, "w"), indent=1)
