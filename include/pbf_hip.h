@@ -88,8 +88,10 @@ int pbf_abi_version(void);
  * bracketed with events), "row_major" (DEFAULT 1: the solver iterations run on a cell-ROW-major copy of {pStar, lambda,
  * quantised position, mass, type} — one contiguous run per (dy, dz) row of the 27-cell stencil, lists of row slots; 0 =
  * everything in Morton order), "nbr_chunks" (size of the pool of 24-slot overflow chunks of the two-tier neighbour lists;
- * 0 = sized from the particle count).  Every setting of these two is bit-identical.  Unknown names return
- * PBF_ERR_INVALID. */
+ * 0 = sized from the particle count), "row_diffuse" (DEFAULT 1, with row_major: the colour diffusion walks the row-major copy, one
+ * wave per segment of 64 x cells, runs staged by LDS-DMA, sums applied in place; 0 = per-cell sums on the Morton order, beside
+ * the iterations), "diffuse_cap" (diagnostic: records in that kernel's LDS tile, 0 = default 640).  Every setting of these
+ * is bit-identical.  Unknown names return PBF_ERR_INVALID. */
 int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value);
 
 /* ---- particle state (replaces the std::vector<Particle>& in/out argument, src/sph.hpp:124) */

@@ -132,6 +132,7 @@ struct pbf_ctx {
   DevBuf rowPstar[2], rowMass, rowQpos, rowXYZ, rowType, rowSlotOf, linCount, linTable, linSums;
   DevBuf rowCol, rowMortonOf, rowSegs;  // k_diffuse_rows: the colours in row order, slot -> Morton index, non-empty segments
   uint32_t rowSegShift = 0;
+  uint32_t diffuseCap = 0;   // option "diffuse_cap" (diagnostic): records in k_diffuse_rows' tile, 0 = default
   int rowDiffuse = 1;        // option "row_diffuse": the diffusion runs on the row-major copy (k_diffuse_rows)
   bool bricksValid = false;  // ctx->bricks lists the non-empty bricks of the current table
   bool rowColValid = false;  // rowCol holds the colours of col4[cur] (set by the sort, consumed by the diffusion)
@@ -486,6 +487,19 @@ void brick_list(pbf_ctx *ctx, uint32_t tableN, bool counterIsZero = false) {
   ctx->bricksValid = true;
 }
 
+// one to two exclusive scans in three launches (k_scan_sums zeroes `nZero` control words on its way)
+void launch_scans(pbf_ctx *ctx, const ScanJobs &jobs, int njobs, uint32_t *zero = nullptr, uint32_t nZero = 0) {
+  const uint32_t blocks = jobs.nb[0] + (njobs > 1 ? jobs.nb[1] : 0u);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(blocks), dim3(BLOCK), 0, ctx->stream, jobs);
+  hipLaunchKernelGGL(k_scan_sums, dim3(uint32_t(njobs)), dim3(BLOCK), 0, ctx->stream, jobs, zero, nZero);
+  hipLaunchKernelGGL(k_scan_apply, dim3(blocks), dim3(BLOCK), 0, ctx->stream, jobs);
+}
+ScanJobs scan_job(const uint32_t *count, uint32_t len, uint32_t *sums, uint32_t *table) {
+  ScanJobs j{};
+  j.count[0] = count, j.sums[0] = sums, j.table[0] = table, j.len[0] = len, j.nb[0] = (len + SCAN_TILE - 1) / SCAN_TILE;
+  return j;
+}
+
 template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
   // the scatter consumes the histogram k_predict built (atomicSub back to zero): never run it twice
   if (!ctx->counted) return fail(ctx, PBF_ERR_STATE, "pbf_stage_sort needs pbf_stage_predict first");
@@ -497,9 +511,9 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
   const uint32_t nb = (len + SCAN_TILE - 1) / SCAN_TILE;
   uint32_t *count = ctx->count.as<uint32_t>(), *table = ctx->table.as<uint32_t>(),
            *sums = ctx->blockSums.as<uint32_t>();
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(BLOCK), 0, ctx->stream, count, len, sums);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLOCK), 0, ctx->stream, sums, nb);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(BLOCK), 0, ctx->stream, count, len, sums, table);
+  ScanJobs jobs = scan_job(count, len, sums, table);
+  int njobs = 1;
+  (void)nb;
   const int s = ctx->cur, d = 1 - s;
   // option "row_major": the box cells' populations in cell-row-major order and their scan (the row table), read off the
   // Morton table; k_rank_move below then writes the iterations' row-major copy on its way
@@ -530,13 +544,14 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
       if (int rc = ensure(ctx, ctx->rowMortonOf, ctx->cap * 4)) return rc;
       if (int rc = ensure(ctx, ctx->rowSegs, (std::min(nSegTotal, ctx->cap) + 1) * 4)) return rc;
     }
-    hipLaunchKernelGGL(k_lin_count, grid_for(ncells + 1), dim3(BLOCK), 0, ctx->stream, c.tableN, pshift, table,
+    // the cells' populations in row order straight from the histogram, so that both tables' scans share their launches
+    hipLaunchKernelGGL(k_lin_count, grid_for(ncells + 1), dim3(BLOCK), 0, ctx->stream, c.tableN, pshift, count,
                        ctx->linCount.as<uint32_t>());
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(lnb), dim3(BLOCK), 0, ctx->stream, ctx->linCount.as<const uint32_t>(), uint32_t(llen),
-                       ctx->linSums.as<uint32_t>());
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->linSums.as<uint32_t>(), lnb);
-    hipLaunchKernelGGL(k_scan_apply, dim3(lnb), dim3(BLOCK), 0, ctx->stream, ctx->linCount.as<const uint32_t>(), uint32_t(llen),
-                       ctx->linSums.as<const uint32_t>(), ctx->linTable.as<uint32_t>());
+    jobs.count[1] = ctx->linCount.as<const uint32_t>(), jobs.sums[1] = ctx->linSums.as<uint32_t>(), jobs.table[1] = ctx->linTable.as<uint32_t>();
+    jobs.len[1] = uint32_t(llen), jobs.nb[1] = lnb;
+    njobs = 2;
+    // (brickCtl = {nActive bricks, tickets[kTickets], number of big cells}: zeroed once per step, by k_scan_sums on its way)
+    launch_scans(ctx, jobs, njobs, ctx->brickCtl.as<uint32_t>(), kTickets + 2);
     if (rowDiffuse)  // the x-segments that hold a particle (at most one per particle), for k_diffuse_rows
       hipLaunchKernelGGL(k_row_segments, grid_for(nSegTotal), dim3(BLOCK), 0, ctx->stream, pshift, segShift,
                          ctx->linTable.as<const uint32_t>(), ctx->rowSegs.as<uint32_t>(), ctx->linCount.as<uint32_t>() + ncells + 2);
@@ -549,8 +564,7 @@ template <typename N> int stage_sort(pbf_ctx *ctx, const pbf_params *p) {
     ctx->rowColValid = rowDiffuse;
     ctx->rowsValid = true, ctx->rowsCurrent = true;
   }
-  // brickCtl = {nActive bricks, tickets[kTickets], number of big cells}: zeroed once per step
-  HIPCHK(ctx, hipMemsetAsync(ctx->brickCtl.p, 0, (kTickets + 2) * 4, ctx->stream));
+  if (njobs == 1) launch_scans(ctx, jobs, 1, ctx->brickCtl.as<uint32_t>(), kTickets + 2);  // (Morton order only)
   uint32_t *nBig = ctx->brickCtl.as<uint32_t>() + kTickets + 1;
   if (int rc = ensure(ctx, ctx->bigCells, (ctx->cap / BIG_CELL + 2) * 4)) return rc;
   hipLaunchKernelGGL(k_scatter_slots, grid_for(ctx->n), dim3(BLOCK), 0, ctx->stream, c.n, c.tableN,
@@ -776,9 +790,11 @@ template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p, bool 
     // the row-major copy: one wave per segment of 64 x cells, runs staged through LDS, sums applied in place (k_diffuse_rows).
     // On the solver's own stream: the launch is short, nothing is gained by hiding it
     const uint32_t ncells = 1u << (3u * ctx->rowShift);
-    static const uint32_t capEnv = std::getenv("PBF_DIFF_CAP") ? uint32_t(std::atoi(std::getenv("PBF_DIFF_CAP"))) : 0u;  // (experiments)
-    const uint32_t cap = capEnv ? capEnv : 768u;  // records of one row's run (66 cells): the settled dam-break's are ~460 to 600; a longer one walks from memory
-    const size_t lds = size_t(cap) * sizeof(vec4<N>) + size_t(DIFFUSE_ROW_THREADS) * (4 * sizeof(N) + 4) + cap;
+    // records of one row's run in the LDS tile (66 cells; the settled dam-break's are ~460): a longer run walks from memory.
+    // A small tile matters more than a roomy one: 13 single-wave workgroups per CU at 640 records (fp32), and the launch time
+    // is inversely proportional to that number (measured: 1 024 records 68 us, 768 61 us, 640 51 us, 576 51 us)
+    const uint32_t cap = ctx->diffuseCap ? ctx->diffuseCap : 640u;
+    const size_t lds = size_t(cap + 8) * sizeof(vec4<N>) + size_t(DIFFUSE_ROW_THREADS) * (4 * sizeof(N) + 4) + cap;  // (+ 8 records: the fold reads ahead)
     static size_t attrSet = 0;  // per instantiation
     if (lds > attrSet) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_diffuse_rows<N>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
@@ -844,6 +860,16 @@ template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p, bool 
   return PBF_OK;
 }
 
+// the row build's shape: pair loads per trip, staging depth, survivors per drain trip (A/B builds override these)
+#ifndef PBF_ROWS_W
+#define PBF_ROWS_W 4
+#endif
+#ifndef PBF_ROWS_LMAX
+#define PBF_ROWS_LMAX 32
+#endif
+#ifndef PBF_ROWS_FW
+#define PBF_ROWS_FW 4
+#endif
 template <typename N> int stage_lambda(pbf_ctx *ctx, const pbf_params *p) {
   StepConsts<N> c;
   if (int rc = make_consts<N>(ctx, p, c)) return rc;
@@ -858,10 +884,10 @@ template <typename N> int stage_lambda(pbf_ctx *ctx, const pbf_params *p) {
     const RowWalk rw = row_walk<N>(ctx);
     if (ctx->fast) {
       typename LambdaOp<N, true>::Args a{ctx->rowPstar[ctx->rcur].as<vec4<N>>(), nullptr, ctx->rowType.as<const uint8_t>(), ctx->rowMass.as<const N>()};
-      hipLaunchKernelGGL((k_build_rows_op<N, LambdaOp<N, true>, 4, 32, 4>), g, b, 0, ctx->stream, c, a, ctx->rowQpos.as<const uint2>(), rw, nbr_lists(ctx, true));
+      hipLaunchKernelGGL((k_build_rows_op<N, LambdaOp<N, true>, PBF_ROWS_W, PBF_ROWS_LMAX, PBF_ROWS_FW>), g, b, 0, ctx->stream, c, a, ctx->rowQpos.as<const uint2>(), rw, nbr_lists(ctx, true));
     } else {
       typename LambdaOp<N, false>::Args a{ctx->rowPstar[ctx->rcur].as<vec4<N>>(), nullptr, ctx->rowType.as<const uint8_t>(), ctx->rowMass.as<const N>()};
-      hipLaunchKernelGGL((k_build_rows_op<N, LambdaOp<N, false>, 4, 32, 4>), g, b, 0, ctx->stream, c, a, ctx->rowQpos.as<const uint2>(), rw, nbr_lists(ctx, true));
+      hipLaunchKernelGGL((k_build_rows_op<N, LambdaOp<N, false>, PBF_ROWS_W, PBF_ROWS_LMAX, PBF_ROWS_FW>), g, b, 0, ctx->stream, c, a, ctx->rowQpos.as<const uint2>(), rw, nbr_lists(ctx, true));
     }
     LAUNCH_CHECK(ctx);
     ctx->pstarInRows = true, ctx->nbrRows = true;
@@ -1152,6 +1178,10 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
   else if (n == "pad_lds") ctx->padLds = uint32_t(value);
   else if (n == "row_major") ctx->rowMajor = int(value);
   else if (n == "row_diffuse") ctx->rowDiffuse = int(value);
+  else if (n == "diffuse_cap") {
+    if (value < 0 || value > 4096) return fail(ctx, PBF_ERR_INVALID, "diffuse_cap: 0 (default) .. 4096 records");
+    ctx->diffuseCap = uint32_t(value);
+  }
   else if (n == "nbr_chunks") {  // diagnostic: size of the lists' second tier (before the first upload; 0 = capacity / 16 + 1024)
     if (ctx->cap) return fail(ctx, PBF_ERR_STATE, "nbr_chunks must be set before the first upload");
     ctx->nbrChunksOpt = uint32_t(value);
@@ -2368,9 +2398,7 @@ template <typename N> int surface_impl(pbf_ctx *ctx, const pbf_params *p, const 
   HIPCHK(ctx, hipMemsetAsync(counts + marchVolume, 0, 4, ctx->stream));  // closing sentinel: offsets[marchVolume] = total
   hipLaunchKernelGGL((k_mc_count<N>), grid_for(marchVolume), dim3(BLOCK), 0, ctx->stream, m, marchVolume,
                      ctx->latticePN.as<const vec4<N>>(), counts);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(BLOCK), 0, ctx->stream, counts, len, sums);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLOCK), 0, ctx->stream, sums, nb);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(BLOCK), 0, ctx->stream, counts, len, sums, offsets);
+  launch_scans(ctx, scan_job(counts, len, sums, offsets), 1);
   LAUNCH_CHECK(ctx);
   uint32_t total = 0;
   HIPCHK(ctx, hipMemcpyAsync(&total, offsets + marchVolume, 4, hipMemcpyDeviceToHost, ctx->stream));

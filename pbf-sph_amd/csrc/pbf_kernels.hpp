@@ -176,24 +176,40 @@ template <int THREADS = BLOCK> __device__ inline uint32_t block_excl_scan(uint32
   return off + incl - v;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_scan_block_sums(const uint32_t *__restrict__ count, uint32_t len,
-                                                           uint32_t *__restrict__ blockSums) {
-  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+// Up to two independent scans per launch (the Morton grid table and, with the row-major working set, the row table): job 0
+// takes the first nb[0] workgroups, job 1 the rest.
+struct ScanJobs {
+  const uint32_t *count[2];
+  uint32_t *sums[2];
+  uint32_t *table[2];
+  uint32_t len[2], nb[2];
+};
+__global__ __launch_bounds__(BLOCK) void k_scan_block_sums(ScanJobs jobs) {
+  const uint32_t j = blockIdx.x >= jobs.nb[0] ? 1u : 0u, blk = blockIdx.x - (j ? jobs.nb[0] : 0u);
+  const uint32_t *__restrict__ count = jobs.count[j];
+  const uint32_t len = jobs.len[j];
+  const uint32_t base = blk * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
   uint32_t s = 0;
   if (base + SCAN_ITEMS <= len) {
     const uint4 a = *reinterpret_cast<const uint4 *>(count + base);
     const uint4 b = *reinterpret_cast<const uint4 *>(count + base + 4);
     s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
   } else {
-    for (int j = 0; j < SCAN_ITEMS; ++j)
-      if (base + j < len) s += count[base + j];
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+      if (base + k < len) s += count[base + k];
   }
   uint32_t total;
   block_excl_scan(s, &total);
-  if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
+  if (threadIdx.x == 0) jobs.sums[j][blk] = total;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_scan_sums(uint32_t *__restrict__ blockSums, uint32_t nb) {
+// one workgroup per job; on its way it zeroes `nZero` control words (the per-step tickets and counters, which would
+// otherwise cost a fill launch of their own)
+__global__ __launch_bounds__(BLOCK) void k_scan_sums(ScanJobs jobs, uint32_t *__restrict__ zero, uint32_t nZero) {
+  if (blockIdx.x == 0)
+    for (uint32_t k = threadIdx.x; k < nZero; k += BLOCK) zero[k] = 0u;
+  uint32_t *__restrict__ blockSums = jobs.sums[blockIdx.x];
+  const uint32_t nb = jobs.nb[blockIdx.x];
   uint32_t carry = 0;
   for (uint32_t base = 0; base < nb; base += BLOCK) {
     const uint32_t i = base + threadIdx.x;
@@ -205,23 +221,25 @@ __global__ __launch_bounds__(BLOCK) void k_scan_sums(uint32_t *__restrict__ bloc
   }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t *__restrict__ count, uint32_t len,
-                                                      const uint32_t *__restrict__ blockSums,
-                                                      uint32_t *__restrict__ table) {
-  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+__global__ __launch_bounds__(BLOCK) void k_scan_apply(ScanJobs jobs) {
+  const uint32_t j = blockIdx.x >= jobs.nb[0] ? 1u : 0u, blk = blockIdx.x - (j ? jobs.nb[0] : 0u);
+  const uint32_t *__restrict__ count = jobs.count[j];
+  uint32_t *__restrict__ table = jobs.table[j];
+  const uint32_t len = jobs.len[j];
+  const uint32_t base = blk * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
   uint32_t v[SCAN_ITEMS];
   uint32_t s = 0;
 #pragma unroll
-  for (int j = 0; j < SCAN_ITEMS; ++j) {
-    v[j] = (base + j < len) ? count[base + j] : 0u;
-    s += v[j];
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    v[k] = (base + k < len) ? count[base + k] : 0u;
+    s += v[k];
   }
   uint32_t total;
-  uint32_t run = block_excl_scan(s, &total) + blockSums[blockIdx.x];
+  uint32_t run = block_excl_scan(s, &total) + jobs.sums[j][blk];
 #pragma unroll
-  for (int j = 0; j < SCAN_ITEMS; ++j) {
-    if (base + j < len) table[base + j] = run;
-    run += v[j];
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    if (base + k < len) table[base + k] = run;
+    run += v[k];
   }
 }
 
@@ -366,9 +384,10 @@ __host__ __device__ inline bool row_cell_of(uint32_t key, uint32_t tableN, uint3
   return key + 1u < tableN;  // (a key >= tableN - 1 is "in no cell" for its neighbours, sph.hpp:206-208; below it, x, y, z < P)
 }
 
-// per cell of the cube: its population, read off the Morton table (one lane per Morton code)
+// per cell of the cube: its population, read off the cell histogram k_predict built (one lane per Morton code) — BEFORE the
+// scans, so that the Morton table's and the row table's run in the same launches
 // (over every code of the cube — a bijection onto its cells, so no memset: a cell the table does not know is written 0)
-__global__ __launch_bounds__(BLOCK) void k_lin_count(uint32_t tableN, uint32_t pshift, const uint32_t *__restrict__ table,
+__global__ __launch_bounds__(BLOCK) void k_lin_count(uint32_t tableN, uint32_t pshift, const uint32_t *__restrict__ count,
                                                      uint32_t *__restrict__ linCount) {
   const uint32_t code = blockIdx.x * BLOCK + threadIdx.x;
   if (code >= (1u << (3u * pshift))) {
@@ -377,7 +396,7 @@ __global__ __launch_bounds__(BLOCK) void k_lin_count(uint32_t tableN, uint32_t p
   }
   uint32_t lin;
   const bool known = row_cell_of(code, tableN, pshift, &lin);
-  linCount[lin] = known ? table[code + 1u] - table[code] : 0u;
+  linCount[lin] = known ? count[code] : 0u;  // (known: code < tableN - 1 — its histogram bin holds exactly the particles with that key)
 }
 
 template <typename N>
@@ -1700,7 +1719,7 @@ __global__ __launch_bounds__(DIFFUSE_ROW_THREADS) void k_diffuse_rows(StepConsts
   constexpr uint32_t UNITS = sizeof(vec4<N>) / 16u;  // 16-byte pieces per record (what one lane of an LDS-DMA moves)
   extern __shared__ __align__(16) unsigned char smem[];
   vec4<N> *tile = reinterpret_cast<vec4<N> *>(smem);                     // [cap] one row's run of colours
-  N *sums = reinterpret_cast<N *>(smem + size_t(cap) * sizeof(vec4<N>));  // [4][T] the cells' sums for the apply pass
+  N *sums = reinterpret_cast<N *>(smem + size_t(cap + 8u) * sizeof(vec4<N>));  // [4][T] the cells' sums for the apply pass (behind the tile and its 8 records of read-ahead padding)
   uint32_t *cnts = reinterpret_cast<uint32_t *>(sums + 4 * T);            // [T]
   uint8_t *flag = reinterpret_cast<uint8_t *>(cnts + T);                  // [cap] candidate types (only with obstacles)
   const uint32_t lane = threadIdx.x, P = 1u << rw.pshift, X = 1u << segShift;
@@ -1726,7 +1745,10 @@ __global__ __launch_bounds__(DIFFUSE_ROW_THREADS) void k_diffuse_rows(StepConsts
     auto add = [&](const vec4<N> &cb) { mx += cb.x, my += cb.y, mz += cb.z, mw += cb.w, ++nn; };
     // the segment's own particles [hs, he), lane l takes hs + l, hs + l + 64, ...: what the apply pass at the end needs of the
     // first OWN x 64 of them is requested now and arrives while the planes are folded
-    constexpr uint32_t OWN = 8;
+#ifndef PBF_DIFF_OWN
+#define PBF_DIFF_OWN 8
+#endif
+    constexpr uint32_t OWN = PBF_DIFF_OWN;
     const uint32_t hs = __shfl(ownS, 0), he = __shfl(ownE, int(X) - 1);
     vec4<N> ownCol[OWN];
     uint32_t ownDst[OWN], ownXyz[OWN];
@@ -1780,10 +1802,26 @@ __global__ __launch_bounds__(DIFFUSE_ROW_THREADS) void k_diffuse_rows(StepConsts
           for (uint32_t j = s; j < e; ++j)
             if (!(flag[j] & 1)) add(tile[j]);  // obstacles are skipped as candidates (ompsph.hpp:194)
         } else {
-#pragma unroll 4
-          for (uint32_t j = s; j < e; ++j) {
-            const vec4<N> cb = tile[j];
-            mx += cb.x, my += cb.y, mz += cb.z, mw += cb.w;
+          // four records per trip, the next four requested before these are added (reads past the sub-run stay inside the
+          // tile's padding and are never added): one LDS latency per row instead of one per trip, no remainder loop
+          const uint32_t cnt = e - s;  // (a lane without a sub-run: 0 — its s is meaningless)
+          if (cnt) {
+            vec4<N> cur[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) cur[k] = tile[s + k];
+            uint32_t done = 0;
+            for (; done + 4u <= cnt; done += 4u) {
+              vec4<N> nxt[4];
+#pragma unroll
+              for (uint32_t k = 0; k < 4; ++k) nxt[k] = tile[s + done + 4u + k];
+#pragma unroll
+              for (uint32_t k = 0; k < 4; ++k) mx += cur[k].x, my += cur[k].y, mz += cur[k].z, mw += cur[k].w;
+#pragma unroll
+              for (uint32_t k = 0; k < 4; ++k) cur[k] = nxt[k];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k)
+              if (done + k < cnt) mx += cur[k].x, my += cur[k].y, mz += cur[k].z, mw += cur[k].w;
           }
           nn += e - s;
         }
@@ -1793,18 +1831,24 @@ __global__ __launch_bounds__(DIFFUSE_ROW_THREADS) void k_diffuse_rows(StepConsts
       }
     }
     __syncthreads();
-    sums[lane] = mx, sums[T + lane] = my, sums[2 * T + lane] = mz, sums[3 * T + lane] = mw, cnts[lane] = nn;
+    {  // what every particle of the cell would compute from the sums (DiffuseOp::end: y = (m / n) * 1.33), once per cell
+      const N fn = N(nn ? nn : 1u);
+      sums[lane] = (mx / fn) * N(1.33), sums[T + lane] = (my / fn) * N(1.33), sums[2 * T + lane] = (mz / fn) * N(1.33),
+      sums[3 * T + lane] = (mw / fn) * N(1.33), cnts[lane] = nn;
+    }
     __syncthreads();
     auto apply = [&](const vec4<N> &ca, uint32_t dst, uint32_t xyz, uint8_t ty) {
-      if (typed && ty != 0) {  // obstacle, or a ghost copy owned by the neighbouring slab: unchanged
+      const uint32_t cx = (xyz & 1023u) - x0;
+      if ((typed && ty != 0) || cnts[cx] == 0u) {  // obstacle, or a ghost copy owned by the neighbouring slab; nobody around: unchanged
         colOut[dst] = ca;
         return;
       }
-      DiffuseOp<N> op;
-      op.ca = ca;
-      const uint32_t cx = (xyz & 1023u) - x0;
-      op.mx = sums[cx], op.my = sums[T + cx], op.mz = sums[2 * T + cx], op.mw = sums[3 * T + cx], op.nn = int(cnts[cx]);
-      op.end(c, out, dst);
+      const N t = c.diffuseT;
+      auto one = [&](N x, N y) {  // (= DiffuseOp::end)
+        const N o = x * (N(1) - t) + y * t;
+        return min(max(o, N(0.03)), N(1.0));
+      };
+      colOut[dst] = make_vec4<N>(one(ca.x, sums[cx]), one(ca.y, sums[T + cx]), one(ca.z, sums[2 * T + cx]), one(ca.w, sums[3 * T + cx]));
     };
 #pragma unroll
     for (uint32_t k = 0; k < OWN; ++k)
@@ -1858,14 +1902,25 @@ __global__ __launch_bounds__(BLOCK) void k_build_rows_op(StepConsts<N> c, typena
     return uint32_t(qdot2(__builtin_bit_cast(uint32_t, dzw), qdot2(__builtin_bit_cast(uint32_t, dxy)))) <= t2;
   };
   NbrWriter wr(lists, chunk, tid);
-  // the staging list's write cursor as an LDS BYTE offset (slot s of this lane at s * SLOT + tid * 4): appending is one
-  // store and "cursor += hit ? SLOT : 0" — a select and a full-rate add instead of select + add-with-carry + shift-or
+  // the staging list's write cursor as an LDS ADDRESS (slot s of this lane at lbase + s * SLOT): appending is one store through
+  // the cursor and "cursor += hit ? SLOT : 0" — a select and a full-rate add, no address arithmetic per candidate.  (The
+  // cursor is a 32-bit LDS address kept opaque to the compiler, which otherwise rewrites it as base + offset and adds the
+  // base again before every store.)
   constexpr uint32_t SLOT = BLOCK * 4u;
-  unsigned char *const lbase = reinterpret_cast<unsigned char *>(list) + tid * 4u;
-  auto staged = [&](uint32_t byteOff) -> uint32_t & { return *reinterpret_cast<uint32_t *>(lbase + byteOff); };
-  uint32_t written = 0, cur = 0;
+  typedef __attribute__((address_space(3))) uint32_t *LdsWord;
+  unsigned char *const lbasePtr = reinterpret_cast<unsigned char *>(list) + tid * 4u;
+  const uint32_t lbase = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lbasePtr));
+  const uint32_t lfull = lbase + uint32_t(LMAX) * SLOT;  // the cursor of a lane whose LMAX slots are taken
+  auto staged = [&](uint32_t byteOff) -> uint32_t & { return *reinterpret_cast<uint32_t *>(lbasePtr + byteOff); };
+  auto append = [&](uint32_t &cursor, uint32_t value, bool keep) {
+    *(LdsWord)(uintptr_t)cursor = value;
+    cursor += keep ? SLOT : 0u;
+    asm volatile("" : "+v"(cursor));
+  };
+  uint32_t written = 0;
+  uint32_t cur = lbase;
   auto flush = [&]() {
-    const uint32_t nl = cur / SLOT;
+    const uint32_t nl = uint32_t(cur - lbase) / SLOT;
     wr.reserve(lists, written, nl);
     for (uint32_t q = 0; __any(q < nl); q += FW) {  // FW survivors per trip: their gathers and pair terms interleave
       uint32_t b[FW];
@@ -1880,7 +1935,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_rows_op(StepConsts<N> c, typena
       for (uint32_t w = 0; w < FW; ++w) op.add_bf(c, cnd[w], q + w < nl);
     }
     written += nl;
-    cur = 0;
+    cur = lbase;
   };
   const uint32_t cell = rw.xyz[i];
   const bool slow = (cell & ROW_FALLBACK) != 0u;
@@ -1890,18 +1945,17 @@ __global__ __launch_bounds__(BLOCK) void k_build_rows_op(StepConsts<N> c, typena
       row_for_each_candidate(rw, i, [&](uint32_t b) {
         const uint2 q = qpos[b];
         if (within(q.x, q.y)) {
-          if (cur >= uint32_t(LMAX) * SLOT) {  // (lane-private drain: the others of the wave are not here)
-            const uint32_t nl = cur / SLOT;
+          if (cur >= lfull) {  // (lane-private drain: the others of the wave are not here)
+            const uint32_t nl = uint32_t(cur - lbase) / SLOT;
             wr.reserve(lists, written, nl);
             for (uint32_t k = 0; k < nl; ++k) {
               const uint32_t e = staged(k * SLOT);
               wr.put(written + k, e, true);
               op.add_bf(c, Op::load(args, e), true);
             }
-            written += nl, cur = 0;
+            written += nl, cur = lbase;
           }
-          staged(cur) = b;
-          cur += SLOT;
+          append(cur, b, true);
         }
       });
   }
@@ -1914,23 +1968,26 @@ __global__ __launch_bounds__(BLOCK) void k_build_rows_op(StepConsts<N> c, typena
     if (r < 8) next = load_run(r + 1);
     const uint32_t L = run.e - run.s;
     uint32_t off = run.s * 8u, b0 = run.s;  // byte offset of / row slot at the trip's first candidate
-    for (uint32_t t = 0; __any(t < L); t += 2 * W) {
-      if (t < L) {
-        QPair cnd[W];
+    // (two nested loops: the inner one — trips until a lane's staging list is full or the row is done — touches no state of
+    // the drain, so its loop-carried registers are the walk's own four; with the drain inside the trip loop the compiler
+    // copied the op's accumulators and the writer's state at the head of every trip: 8 v_mov per trip)
+    for (uint32_t t = 0; __any(t < L);) {
+      do {
+        if (t < L) {
+          QPair cnd[W];
 #pragma unroll
-        for (uint32_t w = 0; w < W; ++w) cnd[w] = *reinterpret_cast<const QPair *>(qbase + off + 16u * w);  // (slots past L: padding / the next run, masked)
+          for (uint32_t w = 0; w < W; ++w) cnd[w] = *reinterpret_cast<const QPair *>(qbase + off + 16u * w);  // (slots past L: padding / the next run, masked)
 #pragma unroll
-        for (uint32_t w = 0; w < W; ++w) {
-          const bool hit0 = (t + 2 * w < L) & within(cnd[w].ax, cnd[w].ay);
-          staged(cur) = b0 + 2 * w;  // branch-free append: the slot is kept only on a hit
-          cur += hit0 ? SLOT : 0u;
-          const bool hit1 = (t + 2 * w + 1 < L) & within(cnd[w].bx, cnd[w].by);
-          staged(cur) = b0 + 2 * w + 1u;
-          cur += hit1 ? SLOT : 0u;
+          for (uint32_t w = 0; w < W; ++w) {
+            const bool hit0 = (t + 2 * w < L) & within(cnd[w].ax, cnd[w].ay);
+            append(cur, b0 + 2 * w, hit0);  // branch-free: the slot is kept only on a hit
+            const bool hit1 = (t + 2 * w + 1 < L) & within(cnd[w].bx, cnd[w].by);
+            append(cur, b0 + 2 * w + 1u, hit1);
+          }
         }
-      }
-      off += 16u * W, b0 += 2 * W;
-      if (__any(cur >= uint32_t(LMAX) * SLOT)) flush();
+        off += 16u * W, b0 += 2 * W, t += 2 * W;
+      } while (__any(t < L) && !__any(cur >= lfull));
+      if (__any(cur >= lfull)) flush();
     }
   }
   flush();

@@ -202,6 +202,31 @@ def test_cell_diffuse_bit_exact(pkg, oracle, cell):
 
 
 @pytest.mark.parametrize("fp64", [False, True])
+@pytest.mark.parametrize("row_diffuse,cap", [(1, 0), (1, 24), (1, 1), (0, 0)])
+def test_row_diffuse_bit_exact(pkg, oracle, fp64, row_diffuse, cap):
+    """Option row_diffuse (default 1, with row_major): the colour walk per cell on the row-major copy, one wave per 64-cell
+    x-segment, runs staged through an LDS tile by LDS-DMA, sums applied in place (k_diffuse_rows).  Same candidates in the
+    same order as the reference walk => the same bits as the oracle, and as the Morton-order per-cell walk (row_diffuse 0).
+    cap = the tile in records: 24 and 1 force the walk-from-memory path for most / all rows.  With and without obstacles
+    (skipped as candidates, unchanged as walkers) and with colours that differ per particle."""
+    rng = np.random.default_rng(7)
+    for obstacles in (False, True):
+        sc, side = get_scene(pkg, "dam8192", fp64)
+        sc = {k: v.copy() for k, v in sc.items()}
+        sc["colour"][:] = rng.uniform(0.03, 1.0, sc["colour"].shape).astype(sc["colour"].dtype)
+        if obstacles:
+            sc["type"][::13] = 1
+        s, o = mk(pkg, oracle, sc, fp64)
+        s.set_option("row_diffuse", row_diffuse)
+        s.set_option("diffuse_cap", cap)
+        p, q = params_pair(pkg, oracle, side=side)
+        for frame in range(4):
+            s.step(p)
+            o.step(q)
+            assert_state_equal(s.download(), o.get_particles(), f"row_diffuse={row_diffuse} cap={cap} obstacles={obstacles} frame {frame}")
+
+
+@pytest.mark.parametrize("fp64", [False, True])
 @pytest.mark.parametrize("pipeline", [0, 1])
 def test_pipelined_readers_bit_exact(pkg, oracle, pipeline, fp64):
     """Option pipeline: software-pipelined list-driven lambda / delta-p (default: fp64 only) — same candidates in the same

@@ -11,4 +11,4 @@ done <<'SETS'
 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA
 SETS
-python3 $R/tools/pmc_sq_summary.py $O/sq $O/pmc_sq.md $O/limiter.json > /dev/null; cut -c1-260 $O/pmc_sq.md | head -30
+python3 $R/tools/pmc_table.py $O
