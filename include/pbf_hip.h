@@ -112,6 +112,12 @@ typedef struct pbf_aos_layout {
 } pbf_aos_layout;
 int pbf_upload_aos(pbf_ctx *ctx, size_t n, const void *particles, const pbf_aos_layout *layout);
 int pbf_download_aos(pbf_ctx *ctx, void *particles, const pbf_aos_layout *layout);
+/* The same download in two halves: _begin packs the image and starts its DMA on a copy stream of its own, _end waits for it.
+ * Work enqueued in between that only READS the particle state — pbf_surface, in the shim's advance() — runs while the
+ * particles travel over PCIe (1 M particles: 1.1 ms hidden behind 1.0 ms of surface kernels).  `particles` must stay valid
+ * until _end; no step, upload or stage call in between. */
+int pbf_download_aos_begin(pbf_ctx *ctx, void *particles, const pbf_aos_layout *layout);
+int pbf_download_aos_end(pbf_ctx *ctx);
 
 /* ---- the hot path ---------------------------------------------------------------------- */
 /* One advance() on device-resident state (src/omp/ompsph.hpp:128-271 + 479-481), asynchronous

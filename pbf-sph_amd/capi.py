@@ -110,6 +110,8 @@ _SIGS = {
     "pbf_count": (C.c_size_t, [C.c_void_p]),
     "pbf_upload_aos": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(AosLayout)]),
     "pbf_download_aos": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(AosLayout)]),
+    "pbf_download_aos_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(AosLayout)]),
+    "pbf_download_aos_end": (C.c_int, [C.c_void_p]),
     "pbf_step": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "pbf_steps": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_uint32]),
     "pbf_sync": (C.c_int, [C.c_void_p]),

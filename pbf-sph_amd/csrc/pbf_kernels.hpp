@@ -415,7 +415,13 @@ __global__ __launch_bounds__(BLOCK) void k_rank_move(StepConsts<N> c, uint32_t n
   if (hi - lo > BIG_CELL) {
     rank = i - lo;  // k_sort_big_cells has sorted this segment
   } else if (b < tableN) {
-    for (uint32_t j = lo; j < hi; ++j) rank += (permTmp[j] < s) ? 1u : 0u;
+    for (uint32_t j = lo; j < hi; j += 4u) {  // four cell mates per trip: their loads are in flight together
+      uint32_t v[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) v[k] = permTmp[min(j + k, hi - 1u)];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) rank += (j + k < hi && v[k] < s) ? 1u : 0u;
+    }
   } else {
     // overflow bucket (particles in no cell): keys differ, order by (key, source index) so that the
     // whole array is exactly the stable sort by key the reference's write-back order implies

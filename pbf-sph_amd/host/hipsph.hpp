@@ -478,9 +478,16 @@ public:
     if (config.surface) {  // ompsph.hpp:277-477
       // the mesh lands in page-locked staging (one DMA); its three vectors are then built on host threads WHILE the
       // particles travel back over PCIe
+      // — and the particles set off BEFORE the surface kernels start (pbf_download_aos_begin: their DMA runs on a copy
+      // stream while the field / count / emit kernels, which only read the state, execute)
+      static const bool early = std::getenv("PBF_SHIM_LATE_DOWNLOAD") == nullptr;  // (A/B switch: the round-2 order)
+      const auto l = layout();
+      xs.resize(pbf_count(ctx_));
+      if (early) check(pbf_download_aos_begin(ctx_, xs.data(), &l), "pbf_download_aos_begin");
       MeshCopy copy(*this, config, scene, result.mesh);
       clk.lap(2);
-      download(xs);
+      if (early) check(pbf_download_aos_end(ctx_), "pbf_download_aos_end");
+      else check(pbf_download_aos(ctx_, xs.data(), &l), "pbf_download_aos");
       clk.lap(3);
       copy.join();
       clk.lap(4);

@@ -569,6 +569,16 @@ def test_aos_roundtrip_and_step(pkg):
     s2 = pkg.Solver(h=0.1)
     s2.upload(**sc).step(p)
     assert np.array_equal(s2.download()["pos"], g["pos"])
+    # the download in two halves (what the shim's advance() does around pbf_surface): a surface extraction and even a
+    # further step enqueued before _end do not change the image that travels
+    c = a.copy()
+    assert L.pbf_download_aos_begin(s.ctx, c.ctypes.data_as(C.c_void_p), C.byref(lay)) == 0
+    assert L.pbf_download_aos_begin(s.ctx, c.ctypes.data_as(C.c_void_p), C.byref(lay)) != 0  # (one at a time)
+    s.surface(p)
+    s.step(p)
+    assert L.pbf_download_aos_end(s.ctx) == 0
+    assert L.pbf_download_aos_end(s.ctx) == 0  # (nothing open: a no-op)
+    assert c.tobytes() == b.tobytes()
 
 
 def test_error_paths(pkg):
