@@ -273,7 +273,7 @@ int ensure_particles(pbf_ctx *ctx, size_t n) {
   // (one allocation: a lane addresses both tiers from its row pointer with a 32-bit word offset — which caps the whole at
   // 2^31 words, i.e. ~45 M particles per GPU; beyond that the pool is left out and longer lists walk)
   const size_t rowWords = ((n + BLOCK - 1) / BLOCK) * size_t(NBR_ROWS) * BLOCK;
-  ctx->nbrChunks = ctx->nbrChunksOpt ? ctx->nbrChunksOpt : uint32_t(n / 16 + 1024);  // (option "nbr_chunks": tests shrink the pool)
+  ctx->nbrChunks = ctx->nbrChunksOpt ? ctx->nbrChunksOpt : uint32_t(n / 8 + 1024);  // (option "nbr_chunks": tests shrink the pool)
   if (rowWords + size_t(ctx->nbrChunks) * NBR_EXTRA >= (size_t(1) << 31)) ctx->nbrChunks = 0;
   ctx->nbrExtraAt = rowWords;
   if (int rc = ensure(ctx, ctx->nbrList, (rowWords + size_t(ctx->nbrChunks) * NBR_EXTRA + 64) * 4)) return rc;
@@ -1186,7 +1186,7 @@ int pbf_set_option(pbf_ctx *ctx, const char *name, int64_t value) {
     if (value < 0 || value > 4096) return fail(ctx, PBF_ERR_INVALID, "diffuse_cap: 0 (default) .. 4096 records");
     ctx->diffuseCap = uint32_t(value);
   }
-  else if (n == "nbr_chunks") {  // diagnostic: size of the lists' second tier (before the first upload; 0 = capacity / 16 + 1024)
+  else if (n == "nbr_chunks") {  // diagnostic: size of the lists' second tier (before the first upload; 0 = capacity / 8 + 1024)
     if (ctx->cap) return fail(ctx, PBF_ERR_STATE, "nbr_chunks must be set before the first upload");
     ctx->nbrChunksOpt = uint32_t(value);
   }
