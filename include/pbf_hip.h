@@ -87,7 +87,7 @@ int pbf_abi_version(void);
  * "overlap_diffuse", "fuse_predict", "pipeline", "graph", "pad_lds", "timing_mask" (bit i = stage i of pbf_stage_times is
  * bracketed with events), "row_major" (DEFAULT 1: the solver iterations run on a cell-ROW-major copy of {pStar, lambda,
  * quantised position, mass, type} — one contiguous run per (dy, dz) row of the 27-cell stencil, lists of row slots; 0 =
- * everything in Morton order), "nbr_chunks" (size of the pool of 56-slot overflow chunks of the two-tier neighbour lists;
+ * everything in Morton order), "nbr_chunks" (size of the pool of 120-slot overflow chunks of the two-tier neighbour lists;
  * 0 = sized from the particle count), "row_diffuse" (DEFAULT 1, with row_major: the colour diffusion walks the row-major copy, one
  * wave per segment of 64 x cells, runs staged by LDS-DMA, sums applied in place; 0 = per-cell sums on the Morton order, beside
  * the iterations), "diffuse_cap" (diagnostic: records in that kernel's LDS tile, 0 = default 640).  Every setting of these
@@ -148,9 +148,9 @@ enum pbf_buffer {
   PBF_BUF_KEYS = 0,   /* uint32[n]  Morton cell key per particle, current device order */
   PBF_BUF_TABLE = 1,  /* uint32[table_size] = the reference's gridTable (sph.hpp:238-250) */
   PBF_BUF_PSTAR = 2,  /* N[4n]: pStar.xyz, lambda */
-  PBF_BUF_NBR_COUNT = 3, /* uint32[n]: neighbour list of each particle after the last list build: low 8 bits = length (<= 96),
+  PBF_BUF_NBR_COUNT = 3, /* uint32[n]: neighbour list of each particle after the last list build: low 8 bits = length (<= 160),
                             upper 24 bits = the pool chunk holding its slots 40..63 when the length exceeds 40 (two-tier
-                            lists, csrc/pbf_kernels.hpp NbrLists); 0xFFFFFFFF = more than 96 survivors (or the chunk pool ran
+                            lists, csrc/pbf_kernels.hpp NbrLists); 0xFFFFFFFF = more than 160 survivors (or the chunk pool ran
                             dry): the particle walks its cells; diagnostic, list gather only */
   PBF_BUF_OMEGA = 4,  /* N[4n]: {omega.xyz, 0}, the vorticity estimate of the last step run with pbf_params.vorticity
                          (opt-in extra, absent from the reference), device order; PBF_ERR_STATE when there is none */

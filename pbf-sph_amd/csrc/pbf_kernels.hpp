@@ -1246,13 +1246,14 @@ __global__ __launch_bounds__(BLOCK) void k_diffuse_apply(StepConsts<N> c, typena
 // particle, a particle with more survivors is marked NBR_OVERFLOW and walks.
 // Two tiers (round 3; the settled dam-break's lists: mean 31, p99 41-44, 1.3 % (1 M) / 4 % (4 M) of the particles above 40
 // — profiles/r03_list_hist.json): the [block][slot][thread] rows hold the first NBR_ROWS = 40 slots of every particle, a
-// particle with more takes ONE chunk of NBR_EXTRA = 56 further slots from a pool (an atomic ticket per such particle and
-// launch; pool = capacity / 8 chunks), 96 slots in all.  192 instead of 260 bytes of list per particle (-26 %);
-// a particle beyond 96, or one that finds the pool empty, is marked NBR_OVERFLOW and walks its cells in the readers.
+// particle with more takes ONE chunk of NBR_EXTRA = 120 further slots from a pool (an atomic ticket per such particle and
+// launch; pool = capacity / 8 chunks), 160 slots in all.  224 instead of 260 bytes of list per particle (-14 %);
+// a particle beyond 160, or one that finds the pool empty, is marked NBR_OVERFLOW and walks its cells in the readers.
 // (The chunk was 24 slots — 64 in all — until the trace showed the SECOND delta-p launch of every step taking 100 us against the
 // others' 57: after the first correction 40 of a million particles sit in transient clumps of 65+ neighbours, each walked
-// its ~200 candidates through the exact pair terms alone, and its wave kept the launch open.  tools/iter_probe.py.)
-constexpr uint32_t NBR_ROWS = 40, NBR_EXTRA = 56, NBR_CAP = NBR_ROWS + NBR_EXTRA;
+// its ~200 candidates through the exact pair terms alone, and its wave kept the launch open.  At 4 M particles the deeper
+// column packs up to 160 — hence 120 slots, of which a list touches only what it fills.  tools/iter_probe.py.)
+constexpr uint32_t NBR_ROWS = 40, NBR_EXTRA = 120, NBR_CAP = NBR_ROWS + NBR_EXTRA;
 constexpr uint32_t NBR_OVERFLOW = 0xFFFFFFFFu;
 constexpr uint32_t NBR_NO_CHUNK = 0xFFFFFFFFu;
 static_assert(NBR_ROWS % 4 == 0 && NBR_EXTRA % 4 == 0 && NBR_CAP < 256, "readers take 4 entries per trip; the length lives in 8 bits");

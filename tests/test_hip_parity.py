@@ -234,12 +234,12 @@ def test_pipelined_readers_bit_exact(pkg, oracle, pipeline, fp64):
     sc, side = get_scene(pkg, "dam8192", fp64)
     sc = {k: v.copy() for k, v in sc.items()}
     sc["type"][::13] = 1
-    sc["pos"][:300] = sc["pos"][0] + (np.arange(300)[:, None] % 7) * 0.5   # > 96 neighbours: rows overflow, particles walk
+    sc["pos"][:300] = sc["pos"][0] + (np.arange(300)[:, None] % 7) * 0.5   # > 160 neighbours: rows overflow, particles walk
     s, o = mk(pkg, oracle, sc, fp64)
     s.set_option("pipeline", pipeline)
     p, q = params_pair(pkg, oracle, side=side)
     # the pile really overflows its rows (so the readers' walking fallback is what is being compared): the first list
-    # build of the run marks more than 96 survivors as NBR_OVERFLOW
+    # build of the run marks more than 160 survivors as NBR_OVERFLOW
     probe = pkg.Solver(h=0.1, fp64=fp64)
     probe.set_option("pipeline", pipeline)
     probe.upload(**sc).stage("predict", p).stage("sort", p).stage("lambda", p)
@@ -252,16 +252,16 @@ def test_pipelined_readers_bit_exact(pkg, oracle, pipeline, fp64):
 
 @pytest.mark.parametrize("split,pipeline,chunks", [(8, 0, 0), (8, 1, 0), (5, 0, 0), (0, 0, 0), (8, 0, 3), (8, 0, 1)])
 def test_two_tier_lists_bit_exact(pkg, oracle, split, pipeline, chunks):
-    """The neighbour lists keep 40 slots per particle in [block][slot][thread] rows and take a 56-slot chunk from a pool for
+    """The neighbour lists keep 40 slots per particle in [block][slot][thread] rows and take a 120-slot chunk from a pool for
     the few longer ones (NbrLists, csrc/pbf_kernels.hpp).  A scene with all three kinds of particle — lists within the rows,
-    lists that spill into a chunk (41..96 survivors), lists beyond 96 (NBR_OVERFLOW: the particle walks) — through every
+    lists that spill into a chunk (41..160 survivors), lists beyond 160 (NBR_OVERFLOW: the particle walks) — through every
     writer (split_build 8 / 5 / 0) and both readers; and with a pool of 3 chunks / 1 chunk, which most spilling particles
     find empty (they walk instead): identical bits every time."""
     sc, side = get_scene(pkg, "dam8192", False)
     sc = {k: v.copy() for k, v in sc.items()}
     rng = np.random.default_rng(23)
     sc["pos"][:1500] = sc["pos"][4000] + rng.random((1500, 3)).astype(np.float32) * np.float32(95.0)   # ~1.3x the lattice's density
-    sc["pos"][1500:1800] = sc["pos"][0] + (np.arange(300)[:, None] % 7) * 0.5                         # a pile: > 96 neighbours
+    sc["pos"][1500:1800] = sc["pos"][0] + (np.arange(300)[:, None] % 7) * 0.5                         # a pile: > 160 neighbours
     p, q = params_pair(pkg, oracle, side=side)
     probe = pkg.Solver(h=0.1)
     if chunks:
@@ -269,7 +269,7 @@ def test_two_tier_lists_bit_exact(pkg, oracle, split, pipeline, chunks):
     probe.set_option("split_build", split)
     probe.upload(**sc).stage("predict", p).stage("sort", p).stage("lambda", p)
     cnt = probe.nbr_counts()
-    spill = ((cnt > 40) & (cnt <= 96)).sum()
+    spill = ((cnt > 40) & (cnt <= 160)).sum()
     over = (cnt == 0xFFFFFFFF).sum()
     if chunks:
         assert spill <= chunks and over >= 200, (spill, over)     # the pool ran dry: the others walk
