@@ -65,8 +65,8 @@ if limiter_out:
         msg = (f"{top} {shares[top]:.0%} busy by instruction COUNT, waves waiting {e['wave_waiting_frac']:.0%} / "
                f"ready-not-issued {e['wave_ready_not_issued_frac']:.0%} of their life: no unit saturated by count")
         if "k_build" in k:
-            msg += ("; priced by instruction class (compares / selects / v_dot2 / v_pk_sub take 1.7 issue slots, "
-                    "profiles/r02_valu_rates.md) the list build is ~75 % VALU-issue bound (DESIGN.md section 5)")
+            msg += ("; priced by instruction class (fma / add / mul 2 cycles per wave64 instruction on a SIMD, compares / selects / "
+                    "v_dot2 / v_pk_sub ~3.5: profiles/r02_valu_rates.md) the list build is ~75 % VALU-issue bound (DESIGN.md section 5)")
         elif e["wave_waiting_frac"] >= 0.6:
             msg += "; latency bound (waves wait on memory / LDS most of their life)"
         e["measured_limiter"] = msg
