@@ -1290,6 +1290,35 @@ struct NbrWriter {
     if (written <= NBR_ROWS) return written;
     return (written <= NBR_CAP && pooled) ? (written | (chunk << 8)) : NBR_OVERFLOW;
   }
+  // A staged batch [first, first + count) stored with as little per-entry arithmetic as the layout allows: everything that
+  // depends on the lane alone is worked out once per batch (byte offsets from the block's first row word, how many of the
+  // batch's entries land in the rows, how many are stored at all); entry k (wave-uniform) is then one compare, one add and a
+  // store while the whole wave's batch stays inside the rows (the common case: one uniform test per batch), two compares,
+  // two adds and a select otherwise.  put() — slot by slot, 9 VALU per entry with its 64-bit address — was 8 % of the list
+  // build's instructions.
+  struct Batch {
+    uint32_t rowByte0, chunkByte0, kRows, kStore;
+  };
+  __device__ Batch begin_batch(const NbrLists &l, uint32_t tid, uint32_t first, uint32_t count) {
+    reserve(l, first, count);
+    Batch b;
+    b.rowByte0 = (tid + first * BLOCK) * 4u;
+    b.kRows = first < NBR_ROWS ? NBR_ROWS - first : 0u;
+    const uint32_t capLeft = pooled ? (first < NBR_CAP ? NBR_CAP - first : 0u) : b.kRows;
+    b.kStore = min(count, capLeft);
+    b.chunkByte0 = uint32_t(int32_t(tid) + extraDelta + int32_t(first)) * 4u;  // (row[extraDelta + slot] seen from the block's first word)
+    return b;
+  }
+  // blockRows = row - tid (wave-uniform): the stores take a scalar base and a 32-bit lane offset
+  __device__ static void put_rows(uint32_t *blockRows, const Batch &b, uint32_t k, uint32_t value) {
+    if (k < b.kStore) *reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(blockRows) + (b.rowByte0 + k * (BLOCK * 4u))) = value;
+  }
+  __device__ static void put_any(uint32_t *blockRows, const Batch &b, uint32_t k, uint32_t value) {
+    if (k < b.kStore) {
+      const uint32_t off = k < b.kRows ? b.rowByte0 + k * (BLOCK * 4u) : b.chunkByte0 + k * 4u;
+      *reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(blockRows) + off) = value;
+    }
+  }
 };
 // ... and as a reader sees it
 struct NbrReader {
@@ -1912,6 +1941,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_rows_op(StepConsts<N> c, typena
     return uint32_t(qdot2(__builtin_bit_cast(uint32_t, dzw), qdot2(__builtin_bit_cast(uint32_t, dxy)))) <= t2;
   };
   NbrWriter wr(lists, chunk, tid);
+  uint32_t *const blockRows = lists.rows + size_t(chunk) * NBR_ROWS * BLOCK;  // (wave-uniform; wr.row = blockRows + tid)
   // the staging list's write cursor as an LDS ADDRESS (slot s of this lane at lbase + s * SLOT): appending is one store through
   // the cursor and "cursor += hit ? SLOT : 0" — a select and a full-rate add, no address arithmetic per candidate.  (The
   // cursor is a 32-bit LDS address kept opaque to the compiler, which otherwise rewrites it as base + offset and adds the
@@ -1931,7 +1961,8 @@ __global__ __launch_bounds__(BLOCK) void k_build_rows_op(StepConsts<N> c, typena
   uint32_t cur = lbase;
   auto flush = [&]() {
     const uint32_t nl = uint32_t(cur - lbase) / SLOT;
-    wr.reserve(lists, written, nl);
+    const NbrWriter::Batch bt = wr.begin_batch(lists, tid, written, nl);
+    const bool rowsOnly = !__any(written + nl > NBR_ROWS);  // (wave-uniform: nobody's batch reaches beyond the rows)
     for (uint32_t q = 0; __any(q < nl); q += FW) {  // FW survivors per trip: their gathers and pair terms interleave
       uint32_t b[FW];
       typename Op::Src cnd[FW];
@@ -1939,8 +1970,13 @@ __global__ __launch_bounds__(BLOCK) void k_build_rows_op(StepConsts<N> c, typena
       for (uint32_t w = 0; w < FW; ++w) b[w] = q + w < nl ? staged((q + w) * SLOT) : i;
 #pragma unroll
       for (uint32_t w = 0; w < FW; ++w) cnd[w] = Op::load(args, b[w]);
+      if (rowsOnly) {
 #pragma unroll
-      for (uint32_t w = 0; w < FW; ++w) wr.put(written + q + w, b[w], q + w < nl);
+        for (uint32_t w = 0; w < FW; ++w) NbrWriter::put_rows(blockRows, bt, q + w, b[w]);
+      } else {
+#pragma unroll
+        for (uint32_t w = 0; w < FW; ++w) NbrWriter::put_any(blockRows, bt, q + w, b[w]);
+      }
 #pragma unroll
       for (uint32_t w = 0; w < FW; ++w) op.add_bf(c, cnd[w], q + w < nl);
     }
