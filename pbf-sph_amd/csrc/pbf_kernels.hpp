@@ -2083,8 +2083,37 @@ __global__ __launch_bounds__(BLOCK) void k_gather_from_lists(StepConsts<N> c, ty
         op.add(c, pb);
       }
     };
-    if constexpr (ROWS) row_for_each_candidate(rw, i, visit);
-    else for_each_candidate(key[i], table, c.tableN, visit);
+    if constexpr (ROWS) {
+      const uint32_t cell = rw.xyz[i];
+      if (cell & ROW_FALLBACK) {
+        row_for_each_candidate(rw, i, visit);
+      } else {
+        // nine contiguous runs, eight candidates requested per trip: the walker is alone in its wave, so nobody hides its
+        // round trips for it (one candidate at a time, the 40 to 190 walkers of a step held their launch open for 45 us)
+        const uint32_t x = cell & 1023u, y = (cell >> 10) & 1023u, z = (cell >> 20) & 1023u;
+#pragma unroll 1
+        for (uint32_t r = 0; r < 9; ++r) {
+          const RowRun run = row_run(rw, x, y, z, r);
+          for (uint32_t b = run.s; b < run.e; b += 8u) {
+            typename Op::Src pb[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) pb[k] = Op::load(args, min(b + k, run.e - 1u));
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+              if (b + k < run.e) {
+                if constexpr (Op::kFilter) {
+                  if (op.near(c, pb[k])) op.add(c, pb[k]);
+                } else {
+                  op.add(c, pb[k]);
+                }
+              }
+            }
+          }
+        }
+      }
+    } else {
+      for_each_candidate(key[i], table, c.tableN, visit);
+    }
   } else if constexpr (PIPELINED) {
     constexpr uint32_t W = sizeof(N) == 4 ? 4 : 2;
     auto entry = [&](uint32_t slot) { return rd.entry(slot); };
