@@ -797,7 +797,7 @@ template <typename N> int stage_diffuse(pbf_ctx *ctx, const pbf_params *p, bool 
     // A small tile matters more than a roomy one: 13 single-wave workgroups per CU at 640 records (fp32), and the launch time
     // is inversely proportional to that number (measured: 1 024 records 68 us, 768 61 us, 640 51 us, 576 51 us)
     const uint32_t cap = ctx->diffuseCap ? ctx->diffuseCap : 640u;
-    const size_t lds = size_t(cap + 8) * sizeof(vec4<N>) + size_t(DIFFUSE_ROW_THREADS) * (4 * sizeof(N) + 4) + cap;  // (+ 8 records: the fold reads ahead)
+    const size_t lds = size_t(cap + 8) * sizeof(vec4<N>) + size_t(DIFFUSE_ROW_THREADS) * (4 * sizeof(N) + 4) + cap + 8;  // (+ 8 records / types: the fold reads ahead)
     static size_t attrSet = 0;  // per instantiation
     if (lds > attrSet) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_diffuse_rows<N>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));

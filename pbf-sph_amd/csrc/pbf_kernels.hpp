@@ -1765,7 +1765,9 @@ __global__ __launch_bounds__(DIFFUSE_ROW_THREADS) void k_diffuse_rows(StepConsts
   const uint32_t *__restrict__ lintab = rw.lintab;
   const uint32_t nSegs = *nSegsPtr;
   typename DiffuseOp<N>::Args out{nullptr, colOut, nullptr};
-  const bool typed = c.hasObstacles != 0u;
+  // typed: some particle is not plain fluid (an obstacle, or — slab mode — a ghost copy, possibly OF an obstacle): walkers
+  // look at their own type, and the candidates' types are staged beside their colours so that obstacles can be skipped
+  const bool typed = c.hasObstacles != 0u, sift = typed;
   // workgroup -> segment: each XCD (workgroups are dealt to the 8 XCDs round robin) takes a contiguous eighth of the list,
   // so the rows a segment shares with its y / z neighbours are found in that XCD's L2
   const uint32_t xcd = blockIdx.x & 7u, perXcd = gridDim.x >> 3, segsPerXcd = (nSegs + 7u) >> 3;
@@ -1802,7 +1804,7 @@ __global__ __launch_bounds__(DIFFUSE_ROW_THREADS) void k_diffuse_rows(StepConsts
       if (serial)
         for_each_candidate(morton_encode(x, y, z), rw.mtable, rw.tableN, [&](uint32_t b) {
           const uint32_t sl = rw.slotOf[b];
-          if (!(typed && (rowType[sl] & 1))) add(rowCol[sl]);
+          if (!(sift && (rowType[sl] & 1))) add(rowCol[sl]);
         });
     }
     // every table entry of the nine rows first (one round trip): the segment's run [rs, rs + len) and this lane's sub-run
@@ -1832,14 +1834,32 @@ __global__ __launch_bounds__(DIFFUSE_ROW_THREADS) void k_diffuse_rows(StepConsts
         const uint32_t units = len[r] * UNITS;
         for (uint32_t u0 = 0; u0 < units; u0 += T)  // 1 KiB per wave-instruction: lane l's 16 bytes land at dst + 16 l
           if (u0 + lane < units) lds_dma16(src + size_t(u0 + lane) * 16u, dst + size_t(u0) * 16u);
-        if (typed)
-          for (uint32_t k = lane; k < len[r]; k += T) flag[k] = rowType[rs[r] + k];
+        if (sift) {  // the candidates' types: every byte of the run requested before the first is stored
+          constexpr uint32_t FB = 8;
+          for (uint32_t k0 = lane; k0 < len[r]; k0 += FB * T) {
+            uint8_t f[FB];
+#pragma unroll
+            for (uint32_t u = 0; u < FB; ++u) f[u] = rowType[rs[r] + min(k0 + u * T, len[r] - 1u)];
+#pragma unroll
+            for (uint32_t u = 0; u < FB; ++u)
+              if (k0 + u * T < len[r]) flag[k0 + u * T] = f[u];
+          }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every piece has landed
         __syncthreads();
         const uint32_t s = ls[r] - rs[r], e = le[r] - rs[r];
-        if (typed) {
-          for (uint32_t j = s; j < e; ++j)
-            if (!(flag[j] & 1)) add(tile[j]);  // obstacles are skipped as candidates (ompsph.hpp:194)
+        if (sift) {
+          // four records and their types per trip (reads past the sub-run stay inside the padding and are never added)
+          const uint32_t cnt = e - s;
+          for (uint32_t done = 0; done < cnt; done += 4u) {
+            vec4<N> v4[4];
+            uint8_t f4[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) v4[k] = tile[s + done + k], f4[k] = flag[s + done + k];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+              if (done + k < cnt && !(f4[k] & 1)) add(v4[k]);  // obstacles are skipped as candidates (ompsph.hpp:194)
+          }
         } else {
           // four records per trip, the next four requested before these are added (reads past the sub-run stay inside the
           // tile's padding and are never added): one LDS latency per row instead of one per trip, no remainder loop
@@ -1866,7 +1886,7 @@ __global__ __launch_bounds__(DIFFUSE_ROW_THREADS) void k_diffuse_rows(StepConsts
         }
       } else {  // a run longer than the tile (a pile-up): straight from memory
         for (uint32_t j = ls[r]; j < le[r]; ++j)
-          if (!(typed && (rowType[j] & 1))) add(rowCol[j]);
+          if (!(sift && (rowType[j] & 1))) add(rowCol[j]);
       }
     }
     __syncthreads();
@@ -1906,7 +1926,7 @@ __global__ __launch_bounds__(DIFFUSE_ROW_THREADS) void k_diffuse_rows(StepConsts
       continue;
     }
     row_for_each_candidate(rw, j, [&](uint32_t b) {
-      if (!(typed && (rowType[b] & 1))) op.add(c, rowCol[b]);
+      if (!(sift && (rowType[b] & 1))) op.add(c, rowCol[b]);
     });
     op.end(c, out, dst);
   }
