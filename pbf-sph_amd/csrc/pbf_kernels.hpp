@@ -1297,7 +1297,8 @@ struct NbrWriter {
   // two adds and a select otherwise.  put() — slot by slot, 9 VALU per entry with its 64-bit address — was 8 % of the list
   // build's instructions.
   struct Batch {
-    uint32_t rowByte0, chunkByte0, kRows, kStore;
+    uint32_t rowByte0, kRows, kStore;
+    uint64_t chunkByte0;  // (the pool may lie more than 4 GB behind the block's rows: beyond ~19 M particles)
   };
   __device__ Batch begin_batch(const NbrLists &l, uint32_t tid, uint32_t first, uint32_t count) {
     reserve(l, first, count);
@@ -1306,7 +1307,7 @@ struct NbrWriter {
     b.kRows = first < NBR_ROWS ? NBR_ROWS - first : 0u;
     const uint32_t capLeft = pooled ? (first < NBR_CAP ? NBR_CAP - first : 0u) : b.kRows;
     b.kStore = min(count, capLeft);
-    b.chunkByte0 = uint32_t(int32_t(tid) + extraDelta + int32_t(first)) * 4u;  // (row[extraDelta + slot] seen from the block's first word)
+    b.chunkByte0 = uint64_t(int64_t(tid) + int64_t(extraDelta) + int64_t(first)) * 4u;  // (row[extraDelta + slot] seen from the block's first word)
     return b;
   }
   // blockRows = row - tid (wave-uniform): the stores take a scalar base and a 32-bit lane offset
@@ -1315,7 +1316,7 @@ struct NbrWriter {
   }
   __device__ static void put_any(uint32_t *blockRows, const Batch &b, uint32_t k, uint32_t value) {
     if (k < b.kStore) {
-      const uint32_t off = k < b.kRows ? b.rowByte0 + k * (BLOCK * 4u) : b.chunkByte0 + k * 4u;
+      const uint64_t off = k < b.kRows ? uint64_t(b.rowByte0 + k * (BLOCK * 4u)) : b.chunkByte0 + k * 4u;
       *reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(blockRows) + off) = value;
     }
   }
